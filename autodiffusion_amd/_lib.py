@@ -1,0 +1,98 @@
+"""ctypes binding of libadm_hip.so (see include/adm_hip.h).
+
+The HIP extension IS the product: if the shared library is missing or an entry
+point is absent this module raises -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadm_hip.so")
+ABI_VERSION = 1
+
+
+class AdmError(RuntimeError):
+    pass
+
+
+class StepCoefs(C.Structure):
+    """struct adm_step_coefs (include/adm_hip.h)."""
+    _fields_ = [
+        ("sqrt_recip_ac", C.c_float), ("sqrt_recipm1_ac", C.c_float), ("ac", C.c_float),
+        ("ac_prev", C.c_float), ("coef1", C.c_float), ("coef2", C.c_float),
+        ("log_var_lo", C.c_float), ("log_var_hi", C.c_float), ("fixed_var", C.c_float),
+        ("eta", C.c_float), ("nonzero", C.c_int32), ("learned_range", C.c_int32),
+        ("predict_xstart", C.c_int32), ("clip_denoised", C.c_int32),
+    ]
+
+
+class ConvArgs(C.Structure):
+    """struct adm_conv_args (include/adm_hip.h)."""
+    _fields_ = [
+        ("in0", C.c_void_p), ("in1", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+        ("aff_a", C.c_void_p), ("aff_b", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+        ("cout", C.c_int32), ("taps", C.c_int32), ("prologue", C.c_int32), ("out_mode", C.c_int32),
+        ("variant", C.c_int32),
+    ]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+
+# name -> (restype, argtypes); every symbol declared in include/adm_hip.h
+SIGNATURES = {
+    "adm_abi_version": (_I, []),
+    "adm_last_error": (C.c_char_p, []),
+    "adm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(StepCoefs), _P]),
+    "adm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(StepCoefs), _P]),
+    "adm_pack_u8_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "adm_timestep_embedding": (_I, [_P, _P, _I, _I, _F, _P]),
+    "adm_linear_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "adm_stem_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_gn_partial": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "adm_gn_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "adm_resample": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_conv": (_I, [C.POINTER(ConvArgs), _P]),
+    "adm_packed_weight_elems": (C.c_int64, [_I, _I, _I]),
+    "adm_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
+    "adm_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library; raise AdmError if it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm ships its own libamdhip64.so.7; import it FIRST so that the dynamic loader binds
+    # our library to the same HIP runtime instance (shared streams / device pointers).  Loading ours
+    # first would bring in /opt/rocm's copy and leave torch without a usable device.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise AdmError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C autodiffusion_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "There is no CPU/PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise AdmError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.adm_abi_version()
+    if v != ABI_VERSION:
+        raise AdmError(f"libadm_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().adm_last_error().decode("utf-8", "replace")
+        raise AdmError(f"{what} failed (status {status}): {msg}")

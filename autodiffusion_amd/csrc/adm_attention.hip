@@ -1,0 +1,210 @@
+// K5: QKVAttention / QKVAttentionLegacy as a flash-style MFMA kernel (gfx950).
+//
+// Replaces reference guided_diffusion/unet.py:361-393 (new order) and :328-358 (legacy order):
+//   w = softmax_fp32((q*s) . (k*s)), s = ch^-1/4;  a = w . v
+// without materialising the [T, T] weight matrix.  Input is the token-major output of the qkv 1x1
+// projection, bf16 [N][T][3*H*D]; output bf16 [N][T][H*D].
+//
+// Formulation (all MFMAs are v_mfma_f32_16x16x32_bf16):
+//   S^T[key][query] = K . Q^T        A = K rows from LDS, B = Q^T held in registers
+//   online softmax over keys: keys live in the 4 accumulator registers and the 4 lane quarters of
+//   a query column, so the row max/sum need two cross-lane shuffles (xor 16, 32) per tile
+//   O^T[d][query] += V^T . P^T       B = P^T taken straight from the S^T accumulators (the k-order
+//   of the contraction is permuted identically on the V^T side, so P never touches LDS);
+//   A = V^T staged transposed in LDS
+// Block = 4 waves x 32 queries; K/V tiles of 64 keys shared through LDS.
+#include "adm_common.h"
+
+namespace {
+
+constexpr int KT = 64;        // keys per tile
+constexpr int QW = 32;        // queries per wave
+constexpr int QB = 128;       // queries per block
+constexpr int PADE = 8;       // bf16 elements of row padding
+
+struct AttnK {
+  const uint16_t* qkv; uint16_t* out;
+  int T, heads, C3, C;
+  int q_off, k_off, v_off, head_stride;
+  float scale_log2;  // log2(e) / sqrt(D)
+};
+
+template <int D>
+__global__ void __launch_bounds__(256)
+attn_kernel(const AttnK p) {
+  constexpr int KS = D / 32;   // k-steps of QK^T
+  constexpr int DT = D / 16;   // d tiles of the output
+  constexpr int KROW = D + PADE, VROW = KT + PADE;
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[D * VROW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
+  const int qbase = blockIdx.x * QB + wave * QW;
+  const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
+  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
+            vcol = p.v_off + hd * p.head_stride;
+
+  // Q^T fragments: lane (query lc, quarter lq) holds Q[query][ks*32 + 8*lq .. +8]
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qbase + qt * 16 + lc;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (q < p.T) v = *reinterpret_cast<const uint4*>(base + (long long)q * p.C3 + qcol + ks * 32 + lq * 8);
+      qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  f32x4 oacc[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+
+  const int ntiles = (p.T + KT - 1) / KT;
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int k0 = kt0 * KT;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K (row-major) and V (transposed) tiles
+    constexpr int UNITS = KT * D / 8;
+#pragma unroll
+    for (int u0 = 0; u0 < UNITS; u0 += 256) {
+      const int u = u0 + tid;
+      if (u < UNITS) {
+        const int key = u / (D / 8), sg = u % (D / 8);
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (k0 + key < p.T) {
+          const uint16_t* row = base + (long long)(k0 + key) * p.C3;
+          kv = *reinterpret_cast<const uint4*>(row + kcol + sg * 8);
+          vv = *reinterpret_cast<const uint4*>(row + vcol + sg * 8);
+        }
+        *reinterpret_cast<uint4*>(&Ks[key * KROW + sg * 8]) = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Vt[(sg * 8 + 2 * e) * VROW + key] = (uint16_t)(w[e] & 0xffffu);
+          Vt[(sg * 8 + 2 * e + 1) * VROW + key] = (uint16_t)(w[e] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T  (4 key tiles x 2 query tiles)
+    f32x4 st[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kt][qt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (per query column)
+    bf16x8 pf[2][2];  // [query tile][32-key block]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + kt * 16 + lq * 4 + r;
+          float s = st[kt][qt][r];
+          if (key >= p.T) s = -1e30f;
+          st[kt][qt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = exp2f((m_run[qt] - m_new) * p.scale_log2);
+      m_run[qt] = m_new;
+      float psum = 0.f;
+      float pv[4][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f((st[kt][qt][r] - m_new) * p.scale_log2);
+          pv[kt][r] = e;
+          psum += e;
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (__bf16)pv[2 * kb + (e >> 2)][e & 3];
+        pf[qt][kb] = f;
+      }
+    }
+    // ---- O^T += V^T . P^T ; contraction slot k = 8*lq + e  <->  key kb*32 + 16*(e>>2) + 4*lq + (e&3)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const uint16_t* vr = &Vt[(dt * 16 + lc) * VROW + kb * 32 + lq * 4];
+        const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kb], oacc[dt][qt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds d = dt*16 + 4*lq .. +3 of query lc
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const int q = qbase + qt * 16 + lc;
+    if (q >= p.T) continue;
+    uint16_t* orow = p.out + ((long long)n * p.T + q) * p.C + hd * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x4 o = oacc[dt][qt] * inv;
+      uint2 pk;
+      pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+      *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, int d, int new_order,
+                             void* stream) {
+  ADM_REQUIRE(qkv && out, ADM_E_ARG, "adm_attention: null pointer");
+  ADM_REQUIRE(n > 0 && t > 0 && heads > 0, ADM_E_ARG, "adm_attention: bad shape n=%d t=%d heads=%d", n, t, heads);
+  ADM_REQUIRE(d == 32 || d == 64 || d == 128, ADM_E_SHAPE, "adm_attention: head dim %d unsupported (32, 64, 128)", d);
+  ADM_REQUIRE(adm_aligned16(qkv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention: unaligned pointer");
+  ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention: n*heads exceeds grid.y");
+  AttnK k{};
+  k.qkv = qkv; k.out = out; k.T = t; k.heads = heads;
+  k.C = heads * d; k.C3 = 3 * k.C;
+  if (new_order) { k.q_off = 0; k.k_off = k.C; k.v_off = 2 * k.C; k.head_stride = d; }
+  else           { k.q_off = 0; k.k_off = d;   k.v_off = 2 * d;   k.head_stride = 3 * d; }
+  k.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+  dim3 grid((t + QB - 1) / QB, n * heads);
+  hipStream_t s = (hipStream_t)stream;
+  if (d == 32) hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, k);
+  else if (d == 64) hipLaunchKernelGGL((attn_kernel<64>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, k);
+  return adm_check_launch("adm_attention");
+}

@@ -1,0 +1,48 @@
+// Shared helpers for the libadm_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/adm_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// thread-local error text, set by ADM_FAIL / adm_check_launch
+void adm_set_error(const char* fmt, ...);
+
+#define ADM_FAIL(code, ...)        \
+  do {                             \
+    adm_set_error(__VA_ARGS__);    \
+    return (code);                 \
+  } while (0)
+
+#define ADM_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) ADM_FAIL(code, __VA_ARGS__); \
+  } while (0)
+
+static inline int adm_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    adm_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static inline bool adm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+__device__ __forceinline__ float adm_bf16_to_f32(uint16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+__device__ __forceinline__ uint16_t adm_f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float adm_silu(float v) {
+  // v * sigmoid(v);  exp2-based, same fp32 formula on every call site
+  return v / (1.0f + __expf(-v));
+}

@@ -1,0 +1,115 @@
+// K1: timestep embedding and the fp32 embedding MLPs.
+//
+// timestep_embedding (reference guided_diffusion/nn.py:103-121) and the Linear layers fed by
+// it: time_embed (unet.py:470-475), label_emb gather-add (unet.py:652-654) and every ResBlock's
+// emb_layers = SiLU -> Linear (unet.py:199-205), batched across blocks by concatenating the
+// weights along the output dimension.  0.03 % of the UNet's FLOPs; kept in fp32 like the
+// reference (these layers are not converted by convert_to_fp16).
+#include "adm_common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n, int dim, float neg_log_period) {
+  const int half = dim / 2;
+  const int total = n * dim;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / dim, col = i % dim;
+    float v = 0.0f;
+    if (col < 2 * half) {
+      const int k = col < half ? col : col - half;
+      const float freq = expf(neg_log_period * (float)k / (float)half);
+      const float a = t[row] * freq;
+      v = col < half ? cosf(a) : sinf(a);
+    }
+    out[i] = v;
+  }
+}
+
+// out[n, o] = sum_k act(in[n, k]) * w[o, k] + bias[o] (+ table[idx[n], o])
+// 64x64 output tile per 256-thread block, 4x4 outputs per thread, K staged 16 at a time.
+constexpr int LT = 64, LK = 16;
+
+template <bool SILU>
+__global__ void __launch_bounds__(256)
+linear_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+              const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
+              int n, int k, int o) {
+  __shared__ float As[LK][LT + 4];
+  __shared__ float Ws[LK][LT + 4];
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  const int n0 = blockIdx.y * LT, o0 = blockIdx.x * LT;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < k; k0 += LK) {
+    // each thread stages 4 elements of each operand: row r = tid/4 (+0), k-offset (tid%4)*4
+    const int r = threadIdx.x / 4, kk = (threadIdx.x % 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kc = k0 + kk + j;
+      float a = 0.0f, b = 0.0f;
+      if (kc < k) {
+        if (n0 + r < n) {
+          a = in[(long long)(n0 + r) * k + kc];
+          if (SILU) a = adm_silu(a);
+        }
+        if (o0 + r < o) b = w[(long long)(o0 + r) * k + kc];
+      }
+      As[kk + j][r] = a;
+      Ws[kk + j][r] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < LK; ++q) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[j] = As[q][ty * 4 + j];
+        bv[j] = Ws[q][tx * 4 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = n0 + ty * 4 + i;
+    if (row >= n) continue;
+    const float* trow = table ? table + (long long)idx[row] * o : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = o0 + tx * 4 + j;
+      if (col >= o) continue;
+      float v = acc[i][j] + (bias ? bias[col] : 0.0f);
+      if (trow) v += trow[col];
+      out[(long long)row * o + col] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {
+  ADM_REQUIRE(t && out, ADM_E_ARG, "adm_timestep_embedding: null pointer");
+  ADM_REQUIRE(n > 0 && dim > 1 && max_period > 0, ADM_E_ARG, "adm_timestep_embedding: bad args n=%d dim=%d", n, dim);
+  const int total = n * dim;
+  int blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, out, n, dim,
+                     -logf(max_period));
+  return adm_check_launch("adm_timestep_embedding");
+}
+
+extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias, const float* table,
+                              const int64_t* idx, float* out, int n, int k, int o, int silu_in, void* stream) {
+  ADM_REQUIRE(in && w && out, ADM_E_ARG, "adm_linear_f32: null pointer");
+  ADM_REQUIRE(n > 0 && k > 0 && o > 0, ADM_E_ARG, "adm_linear_f32: bad shape n=%d k=%d o=%d", n, k, o);
+  ADM_REQUIRE((table == nullptr) == (idx == nullptr), ADM_E_ARG, "adm_linear_f32: table and idx go together");
+  dim3 grid((o + LT - 1) / LT, (n + LT - 1) / LT);
+  hipStream_t s = (hipStream_t)stream;
+  if (silu_in) hipLaunchKernelGGL((linear_kernel<true>), grid, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+  else hipLaunchKernelGGL((linear_kernel<false>), grid, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+  return adm_check_launch("adm_linear_f32");
+}

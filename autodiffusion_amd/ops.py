@@ -1,0 +1,197 @@
+"""Tensor-level wrappers over the C ABI (include/adm_hip.h).
+
+PyTorch is used here only as the owner of device memory and of the HIP
+stream: every function takes torch tensors, checks dtype / contiguity, and
+passes raw device pointers to libadm_hip.so.  No torch compute op runs on
+the hot path; if the shared library is missing these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AdmError, ConvArgs, StepCoefs, check
+
+BF16 = torch.bfloat16
+GN_EPS = 1e-5
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AdmError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise AdmError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise AdmError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------ sampler
+def sampler_step(kind: str, x, model_out, coefs: StepCoefs, grad=None, noise=None,
+                 want_xstart=False, want_u8=False):
+    """One ddim / ddpm update.  Returns (x_prev, pred_xstart | None, uint8 NHWC | None)."""
+    n, c, h, w = x.shape
+    lib = _lib.load()
+    x_prev = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_xstart else None
+    u8 = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device) if want_u8 else None
+    exp_c = 2 * c if coefs.learned_range else c
+    if tuple(model_out.shape) != (n, exp_c, h, w):
+        raise AdmError(f"model_out shape {tuple(model_out.shape)} != {(n, exp_c, h, w)}")
+    fn = lib.adm_ddim_step if kind == "ddim" else lib.adm_ddpm_step
+    check(fn(_ptr(x, torch.float32, "x"), _ptr(model_out, torch.float32, "model_out"),
+             _ptr(grad, torch.float32, "grad"), _ptr(noise, torch.float32, "noise"),
+             _ptr(x_prev), _ptr(x0), _ptr(u8), n, c, h, w, C.byref(coefs), _stream()),
+          f"adm_{kind}_step")
+    return x_prev, x0, u8
+
+
+def pack_u8_nhwc(x):
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    check(_lib.load().adm_pack_u8_nhwc(_ptr(x, torch.float32, "x"), _ptr(out), n, c, h, w, _stream()),
+          "adm_pack_u8_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------ embeddings
+def timestep_embedding(t, dim: int, max_period: float = 10000.0):
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    check(_lib.load().adm_timestep_embedding(_ptr(t), _ptr(out), t.shape[0], dim, max_period, _stream()),
+          "adm_timestep_embedding")
+    return out
+
+
+def linear_f32(x, w, b=None, silu_in=False, table=None, idx=None, out=None):
+    n, k = x.shape
+    o = w.shape[0]
+    if w.shape[1] != k:
+        raise AdmError(f"linear: weight {tuple(w.shape)} vs input {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty((n, o), dtype=torch.float32, device=x.device)
+    check(_lib.load().adm_linear_f32(_ptr(x, torch.float32, "x"), _ptr(w, torch.float32, "w"),
+                                     _ptr(b, torch.float32, "b"), _ptr(table, torch.float32, "table"),
+                                     _ptr(idx, torch.int64, "idx"), _ptr(out), n, k, o, int(silu_in), _stream()),
+          "adm_linear_f32")
+    return out
+
+
+# ------------------------------------------------------------------ stem / norm / resample
+def stem_conv3x3(x_nchw, w, b):
+    n, cin, h, wd = x_nchw.shape
+    cout = w.shape[0]
+    out = torch.empty((n, h, wd, cout), dtype=BF16, device=x_nchw.device)
+    check(_lib.load().adm_stem_conv3x3(_ptr(x_nchw, torch.float32, "x"), _ptr(w, torch.float32, "w"),
+                                       _ptr(b, torch.float32, "b"), _ptr(out), n, cin, h, wd, cout, _stream()),
+          "adm_stem_conv3x3")
+    return out
+
+
+def gn_slabs(hw: int) -> int:
+    return max(1, min(64, hw // 64))
+
+
+def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None):
+    """GroupNorm32 statistics of the virtual concat (x0 | x1) -> per-(image, channel) affine (a, b).
+
+    film: fp32 view whose row n, columns [0:C) = scale and [C:2C) = shift (row stride film_stride).
+    """
+    n, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    c, hw = c0 + c1, h * w
+    lib = _lib.load()
+    slabs = gn_slabs(hw)
+    if partial is None:
+        partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
+    a = torch.empty((n, c), dtype=torch.float32, device=x0.device)
+    b = torch.empty((n, c), dtype=torch.float32, device=x0.device)
+    check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, _ptr(x1, BF16, "x1"), c1, _ptr(partial), n, hw, slabs, _stream()),
+          "adm_gn_partial")
+    film_ptr = None
+    if film is not None:
+        if film.dtype != torch.float32 or not film.is_cuda:
+            raise AdmError("film must be a float32 device tensor")
+        film_ptr = film.data_ptr()
+    check(lib.adm_gn_finalize(_ptr(partial), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+                              film_ptr, film_stride, _ptr(a), _ptr(b), n, c, hw, slabs, GN_EPS, _stream()),
+          "adm_gn_finalize")
+    return a, b
+
+
+def resample(x, mode: str, aff=None):
+    """mode 'down' = AvgPool2d(2), 'up' = nearest x2; aff=(a, b) applies SiLU(a*x+b) first."""
+    n, h, w, c = x.shape
+    m = {"down": 1, "up": 2}[mode]
+    oh, ow = (h // 2, w // 2) if m == 1 else (h * 2, w * 2)
+    out = torch.empty((n, oh, ow, c), dtype=BF16, device=x.device)
+    a, b = aff if aff is not None else (None, None)
+    check(_lib.load().adm_resample(_ptr(x, BF16, "x"), _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(out),
+                                   n, h, w, c, m, _stream()), "adm_resample")
+    return out
+
+
+# ------------------------------------------------------------------ conv / GEMM
+def pack_conv_weight(w):
+    """fp32 [cout, cin, kh, kw] or [cout, cin, 1] or [cout, cin] -> packed bf16 image (1-D tensor)."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = 1
+    for s in w.shape[2:]:
+        taps *= s
+    lib = _lib.load()
+    elems = lib.adm_packed_weight_elems(cout, cin, taps)
+    if elems < 0:
+        raise AdmError(f"pack_conv_weight: unsupported weight shape {tuple(w.shape)} (cin % 32 == 0, taps 1|9)")
+    w32 = w.detach().to(torch.float32).contiguous()
+    out = torch.empty((elems,), dtype=BF16, device=w.device)
+    check(lib.adm_pack_conv_weight(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight")
+    return out
+
+
+def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
+         out_f32_nchw=False, variant=0, out=None):
+    """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
+
+    x0 (| x1): bf16 NHWC.  Returns bf16 NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].
+    """
+    n, h, w, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    dev = x0.device
+    if out is None:
+        out = (torch.empty((n, cout, h, w), dtype=torch.float32, device=dev) if out_f32_nchw
+               else torch.empty((n, h, w, cout), dtype=BF16, device=dev))
+    a = ConvArgs()
+    a.in0, a.in1 = _ptr(x0, BF16, "x0"), _ptr(x1, BF16, "x1")
+    a.w_packed, a.bias = _ptr(w_packed, BF16, "w_packed"), _ptr(bias, torch.float32, "bias")
+    if aff is not None:
+        a.aff_a, a.aff_b = _ptr(aff[0], torch.float32, "aff_a"), _ptr(aff[1], torch.float32, "aff_b")
+        a.prologue = 2 if silu else 1
+    else:
+        a.prologue = 0
+    a.res = _ptr(res, BF16, "res")
+    a.out = _ptr(out)
+    a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, c1, cout
+    a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
+    check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
+    return out
+
+
+# ------------------------------------------------------------------ attention
+def attention(qkv, heads: int, new_order: bool):
+    """qkv bf16 [N, T, 3*H*D] -> bf16 [N, T, H*D]."""
+    n, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    out = torch.empty((n, t, c), dtype=BF16, device=qkv.device)
+    check(_lib.load().adm_attention(_ptr(qkv, BF16, "qkv"), _ptr(out), n, t, heads, d, int(new_order), _stream()),
+          "adm_attention")
+    return out

@@ -1,0 +1,181 @@
+"""SpacedDiffusion: the reference's sampling interface over the fused HIP step kernel.
+
+Drop-in mirror of the sampling half of ``GaussianDiffusion`` / ``SpacedDiffusion``
+(reference guided_diffusion/gaussian_diffusion.py:441-534 p_sample_loop, :624-716
+ddim_sample_loop incl. AutoDiffusion's ``return_all_images`` and start-noise yield;
+respace.py:63-127 timestep mapping).  Per step, the whole of p_mean_variance +
+condition_score / condition_mean + the x_{t-1} update is ONE launch of
+``adm_ddim_step`` / ``adm_ddpm_step``; the model and cond_fn stay arbitrary
+callables ``(x, t_mapped, **model_kwargs)`` exactly as in the reference.
+
+Training-time members (q_sample, training_losses, bpd, ddim_reverse_sample) are
+out of scope: candidate evaluation never calls them.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import StepCoefs
+from .schedule import (LossType, ModelMeanType, ModelVarType, install_tables, subset_betas)
+
+
+def step_coefs(tables, i: int, *, learned_range: bool, fixed: str = "large", predict_xstart=False,
+               clip_denoised=True, eta=0.0) -> StepCoefs:
+    """Pack step i's scalars (float64 -> float32, as _extract_into_tensor does).
+
+    `tables` is any object/dict exposing the reference's table names."""
+    g = (lambda n: tables[n]) if isinstance(tables, dict) else (lambda n: getattr(tables, n))
+    c = StepCoefs()
+    c.sqrt_recip_ac = float(g("sqrt_recip_alphas_cumprod")[i])
+    c.sqrt_recipm1_ac = float(g("sqrt_recipm1_alphas_cumprod")[i])
+    c.ac = float(g("alphas_cumprod")[i])
+    c.ac_prev = float(g("alphas_cumprod_prev")[i])
+    c.coef1 = float(g("posterior_mean_coef1")[i])
+    c.coef2 = float(g("posterior_mean_coef2")[i])
+    if learned_range:
+        c.log_var_lo = float(g("posterior_log_variance_clipped")[i])
+        c.log_var_hi = float(np.log(g("betas"))[i])
+        c.fixed_var = 0.0
+    elif fixed == "large":
+        v = np.append(g("posterior_variance")[1], g("betas")[1:])
+        c.fixed_var = float(v[i])
+        c.log_var_lo = float(np.log(v)[i])
+        c.log_var_hi = 0.0
+    else:
+        c.fixed_var = float(g("posterior_variance")[i])
+        c.log_var_lo = float(g("posterior_log_variance_clipped")[i])
+        c.log_var_hi = 0.0
+    c.eta = float(eta)
+    c.nonzero = int(i != 0)
+    c.learned_range = int(learned_range)
+    c.predict_xstart = int(predict_xstart)
+    c.clip_denoised = int(clip_denoised)
+    return c
+
+
+class SpacedDiffusion:
+    """A diffusion process over a subset of a base process's timesteps (sampling only)."""
+
+    def __init__(self, use_timesteps, *, betas, model_mean_type, model_var_type, loss_type,
+                 rescale_timesteps=False):
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.rescale_timesteps = rescale_timesteps
+        self.use_timesteps = set(use_timesteps)
+        self.original_num_steps = len(betas)
+        base_ac = np.cumprod(1.0 - np.array(betas, dtype=np.float64), axis=0)
+        new_betas, self.timestep_map = subset_betas(base_ac, self.use_timesteps)
+        install_tables(self, new_betas, allow_single_step=False)
+        if model_mean_type == ModelMeanType.PREVIOUS_X:
+            raise NotImplementedError("ModelMeanType.PREVIOUS_X is not produced by any reference factory")
+        if model_var_type == ModelVarType.LEARNED:
+            raise NotImplementedError("ModelVarType.LEARNED is not produced by any reference factory")
+
+    # ------------------------------------------------------------------ helpers
+    def _coefs(self, i, clip_denoised, eta=0.0):
+        return step_coefs(
+            self, i, learned_range=self.model_var_type == ModelVarType.LEARNED_RANGE,
+            fixed="large" if self.model_var_type == ModelVarType.FIXED_LARGE else "small",
+            predict_xstart=self.model_mean_type == ModelMeanType.START_X,
+            clip_denoised=clip_denoised, eta=eta)
+
+    def _mapped(self, t):
+        """_WrappedModel: step index -> original timestep (float-rescaled if requested)."""
+        map_tensor = torch.tensor(self.timestep_map, device=t.device, dtype=t.dtype)
+        new_ts = map_tensor[t]
+        if self.rescale_timesteps:
+            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+        return new_ts
+
+    def _step(self, kind, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
+              want_u8=False):
+        if denoised_fn is not None:
+            raise NotImplementedError("denoised_fn breaks the fused per-pixel update; no reference script uses it")
+        if model_kwargs is None:
+            model_kwargs = {}
+        idx = t.tolist()
+        if len(set(idx)) != 1:
+            raise NotImplementedError("per-sample step indices: the sample loops always pass one index per batch")
+        i = int(idx[0])
+        ts = self._mapped(t)
+        x = x.contiguous()
+        model_out = model(x, ts, **model_kwargs)
+        if model_out.dtype != torch.float32:
+            model_out = model_out.float()
+        grad = None
+        if cond_fn is not None:
+            grad = cond_fn(x, ts, **model_kwargs).float().contiguous()
+        noise = torch.randn_like(x)  # drawn every step, as the reference does (RNG stream parity)
+        sample, x0, u8 = ops.sampler_step(kind, x, model_out.contiguous(), self._coefs(i, clip_denoised, eta),
+                                          grad, noise, want_xstart=True, want_u8=want_u8)
+        out = {"sample": sample, "pred_xstart": x0}
+        if want_u8:
+            out["uint8_nhwc"] = u8
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
+        return self._step("ddpm", model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs)
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    eta=0.0):
+        return self._step("ddim", model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta)
+
+    def _loop(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+              progress, eta, yield_start):
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        if yield_start:
+            yield {"sample": img}
+        for i in indices:
+            t = torch.tensor([i] * shape[0], device=device)
+            with torch.no_grad():
+                out = self._step(kind, model, img, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta,
+                                 want_u8=(i == 0))
+            yield out
+            img = out["sample"]
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                  cond_fn=None, model_kwargs=None, device=None, progress=False):
+        yield from self._loop("ddpm", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                              device, progress, 0.0, yield_start=False)
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False):
+        final = None
+        for sample in self.p_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn,
+                                                     model_kwargs, device, progress):
+            final = sample
+        self.last_uint8_nhwc = final.get("uint8_nhwc")
+        return final["sample"]
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0):
+        yield from self._loop("ddim", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                              device, progress, eta, yield_start=True)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, return_all_images=False):
+        final = None
+        all_images = []
+        for sample in self.ddim_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn,
+                                                        model_kwargs, device, progress, eta):
+            final = sample
+            if return_all_images:
+                all_images.append(final["sample"])
+        self.last_uint8_nhwc = final.get("uint8_nhwc")
+        if return_all_images:
+            return all_images
+        return final["sample"]
+
+
+__all__ = ["SpacedDiffusion", "step_coefs", "ModelMeanType", "ModelVarType", "LossType"]

@@ -1,0 +1,294 @@
+"""ADM UNet / dynamic (layer-skip) UNet forward on hand-written HIP kernels.
+
+Host-side mirror of the reference model interface (``UNetModel`` reference
+guided_diffusion/unet.py:396-665, ``Dynamic_UNetModel`` dynamic_unet.py:416-702):
+same constructor bookkeeping (via ``arch.build_unet_plan``), the same
+state-dict key layout (so the public ``64x64_diffusion.pt`` etc. load
+unchanged), ``__call__(x, timesteps, y=None[, skip_layer=[]])`` taking and
+returning fp32 NCHW tensors.
+
+Everything between is the MI355X engine: activations are bf16 NHWC in HBM, every
+op is a libadm_hip.so launch (ops.py); PyTorch only owns the memory and the stream.
+Launch sequence per ResBlock (reference unet.py:236-256):
+    gn_partial + gn_finalize           in_layers GroupNorm statistics -> affine
+    conv3x3 [affine+SiLU prologue]     in_layers conv   (virtual concat of the UNet skip)
+    gn_partial + gn_finalize           out_layers GroupNorm + FiLM (1+scale, shift) -> affine
+    [conv1x1]                          skip_connection when channels change
+    conv3x3 [affine+SiLU, +residual]   out_layers conv + skip
+AttentionBlock (unet.py:299-305): gn -> conv1x1 [affine prologue] -> flash attention ->
+conv1x1 [+residual].  The 36 emb_layers Linear projections run as ONE fp32 GEMM per step.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import AdmError
+from .arch import AttnSpec, HeadSpec, ResBlockSpec, StemSpec, UNetPlan
+
+_ZERO_INIT_SUFFIXES = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias")
+
+
+class HipModule:
+    """Minimal parameter container with the subset of nn.Module the search drivers use."""
+
+    def __init__(self, plan: UNetPlan, use_fp16: bool):
+        self.plan = plan
+        self.dtype = torch.float16 if use_fp16 else torch.float32  # reference attribute (unet.py:464)
+        self._params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._packed = None
+        self.training = False
+        g = torch.Generator().manual_seed(0)
+        for name, shape in plan.param_shapes().items():
+            self._params[name] = self._init_param(name, shape, g)
+
+    @staticmethod
+    def _init_param(name, shape, g):
+        # zero_module'd tensors start at zero like the reference; the rest get a fan-in scaled
+        # uniform draw (checkpoints overwrite everything; only the zero pattern is behavioural)
+        if name.endswith(_ZERO_INIT_SUFFIXES) or name in ("out.2.weight", "out.2.bias"):
+            return torch.zeros(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            bound = (1.0 / fan_in) ** 0.5
+            return (torch.rand(shape, generator=g) * 2 - 1) * bound
+        if leaf == "weight":
+            return torch.ones(shape)
+        return torch.zeros(shape)
+
+    # --- nn.Module-like surface -------------------------------------------------
+    def state_dict(self):
+        return OrderedDict(self._params)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing keys {missing[:5]}... "
+                               f"unexpected keys {unexpected[:5]}...")
+        for k, v in sd.items():
+            if k not in self._params:
+                continue
+            v = torch.as_tensor(v)
+            if tuple(v.shape) != tuple(self._params[k].shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(self._params[k].shape)}")
+            self._params[k] = v.detach().to(device=self._params[k].device, dtype=torch.float32).clone()
+        self._packed = None
+        return missing, unexpected
+
+    def parameters(self):
+        return iter(self._params.values())
+
+    def named_parameters(self):
+        return iter(self._params.items())
+
+    def to(self, device):
+        device = torch.device(device)
+        for k in self._params:
+            self._params[k] = self._params[k].to(device)
+        self._packed = None
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("the HIP engine is inference-only (AutoDiffusion is training-free)")
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def convert_to_fp16(self):
+        """Reference API (unet.py:618-624).  The HIP torso always computes in bf16 with fp32
+        accumulate/GroupNorm/softmax; this only records the reference's dtype attribute."""
+        self.dtype = torch.float16
+        return self
+
+    def convert_to_fp32(self):
+        self.dtype = torch.float32
+        return self
+
+    @property
+    def device(self):
+        return next(iter(self._params.values())).device
+
+    def __call__(self, *a, **kw):
+        return self.forward(*a, **kw)
+
+
+class _Prep:
+    """Device-resident, kernel-ready parameters derived from the state dict."""
+    pass
+
+
+class UNetModel(HipModule):
+    def __init__(self, plan: UNetPlan, use_fp16: bool = False):
+        if plan.encoder_only:
+            raise ValueError("use EncoderUNetModel for classifier plans")
+        super().__init__(plan, use_fp16)
+        self.image_size = plan.image_size
+        self.in_channels = plan.in_channels
+        self.model_channels = plan.model_channels
+        self.out_channels = plan.out_channels
+        self.num_classes = plan.num_classes
+        if plan.dynamic:
+            self.layer_num = plan.layer_num
+        for b in plan.all_blocks():
+            if isinstance(b, ResBlockSpec) and not b.scale_shift:
+                raise NotImplementedError("use_scale_shift_norm=False is not built on the HIP path "
+                                          "(every reference launch script sets it True)")
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self):
+        P = self._params
+        dev = self.device
+        if dev.type != "cuda":
+            raise AdmError("UNetModel: parameters are on the CPU; call .to(device) first "
+                           "(the HIP path has no CPU fallback)")
+        pr = _Prep()
+        f32 = lambda k: P[k].to(torch.float32).contiguous()  # noqa: E731
+        pr.te0_w, pr.te0_b = f32("time_embed.0.weight"), f32("time_embed.0.bias")
+        pr.te2_w, pr.te2_b = f32("time_embed.2.weight"), f32("time_embed.2.bias")
+        pr.label = f32("label_emb.weight") if self.plan.num_classes is not None else None
+        # all emb_layers in one [sum(2*cout), emb_dim] matrix; per-block column offsets
+        ws, bs, off = [], [], 0
+        pr.film_off: Dict[str, int] = {}
+        pr.blocks: Dict[str, dict] = {}
+        for b in self.plan.all_blocks():
+            p = b.prefix
+            if isinstance(b, StemSpec):
+                pr.blocks[p] = dict(w=f32(f"{p}.weight"), b=f32(f"{p}.bias"))
+            elif isinstance(b, ResBlockSpec):
+                ws.append(f32(f"{p}.emb_layers.1.weight"))
+                bs.append(f32(f"{p}.emb_layers.1.bias"))
+                pr.film_off[p] = off
+                off += 2 * b.cout
+                d = dict(
+                    g1=f32(f"{p}.in_layers.0.weight"), b1=f32(f"{p}.in_layers.0.bias"),
+                    w1=ops.pack_conv_weight(P[f"{p}.in_layers.2.weight"]), c1b=f32(f"{p}.in_layers.2.bias"),
+                    g2=f32(f"{p}.out_layers.0.weight"), b2=f32(f"{p}.out_layers.0.bias"),
+                    w2=ops.pack_conv_weight(P[f"{p}.out_layers.3.weight"]), c2b=f32(f"{p}.out_layers.3.bias"),
+                )
+                if b.has_skip_conv:
+                    d["ws"] = ops.pack_conv_weight(P[f"{p}.skip_connection.weight"])
+                    d["wsb"] = f32(f"{p}.skip_connection.bias")
+                pr.blocks[p] = d
+            elif isinstance(b, AttnSpec):
+                pr.blocks[p] = dict(
+                    g=f32(f"{p}.norm.weight"), b=f32(f"{p}.norm.bias"),
+                    wqkv=ops.pack_conv_weight(P[f"{p}.qkv.weight"]), bqkv=f32(f"{p}.qkv.bias"),
+                    wproj=ops.pack_conv_weight(P[f"{p}.proj_out.weight"]), bproj=f32(f"{p}.proj_out.bias"),
+                )
+        pr.film_w = torch.cat(ws, dim=0).contiguous()
+        pr.film_b = torch.cat(bs, dim=0).contiguous()
+        pr.film_total = off
+        h = self.plan.head
+        if isinstance(h, HeadSpec):
+            pr.head = dict(g=f32(f"{h.prefix}.0.weight"), b=f32(f"{h.prefix}.0.bias"),
+                           w=ops.pack_conv_weight(P[f"{h.prefix}.2.weight"]), cb=f32(f"{h.prefix}.2.bias"))
+        self._packed = pr
+        return pr
+
+    # ------------------------------------------------------------------ blocks
+    def _resblock(self, pr, s: ResBlockSpec, x0, x1, film, skipped):
+        d = pr.blocks[s.prefix]
+        mode = "up" if s.up else ("down" if s.down else None)
+        if skipped:  # dynamic_unet.py:245-250: body bypassed, x_upd + skip_connection kept
+            xs = ops.resample(x0, mode) if mode else x0
+            if s.has_skip_conv:
+                return ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=x1)
+            return xs
+        aff1 = ops.gn_affine(x0, d["g1"], d["b1"], x1)
+        if mode:
+            assert x1 is None
+            h_in = ops.resample(x0, mode, aff1)
+            xs = ops.resample(x0, mode)
+            h = ops.conv(h_in, d["w1"], d["c1b"], s.cout, 9)
+            xs1 = None
+        else:
+            h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True)
+            xs, xs1 = x0, x1
+        off = pr.film_off[s.prefix]
+        aff2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total)
+        if s.has_skip_conv:
+            res = ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=xs1)
+        else:
+            res = xs
+        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res)
+
+    def _attention(self, pr, s: AttnSpec, x, skipped):
+        if skipped:  # dynamic_unet.py:316-318
+            return x
+        d = pr.blocks[s.prefix]
+        n, hh, ww, c = x.shape
+        aff = ops.gn_affine(x, d["g"], d["b"])
+        qkv = ops.conv(x, d["wqkv"], d["bqkv"], 3 * c, 1, aff=aff, silu=False)
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), s.num_heads, s.new_order)
+        return ops.conv(a.view(n, hh, ww, c), d["wproj"], d["bproj"], c, 1, res=x)
+
+    def _run_seq(self, pr, seq, h, skip, film, skip_ids, x_nchw=None):
+        first = True
+        for blk in seq:
+            if isinstance(blk, StemSpec):
+                d = pr.blocks[blk.prefix]
+                h = ops.stem_conv3x3(x_nchw, d["w"], d["b"])
+            elif isinstance(blk, ResBlockSpec):
+                h = self._resblock(pr, blk, h, skip if first else None, film, blk.layer_id in skip_ids)
+            else:
+                h = self._attention(pr, blk, h, blk.layer_id in skip_ids)
+            first = False
+        return h
+
+    # ------------------------------------------------------------------ forward
+    def _embed(self, pr, timesteps, y):
+        plan = self.plan
+        assert (y is not None) == (plan.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        e = ops.timestep_embedding(timesteps, plan.model_channels)
+        e = ops.linear_f32(e, pr.te0_w, pr.te0_b)
+        if y is not None:
+            assert y.shape == (timesteps.shape[0],)
+            e = ops.linear_f32(e, pr.te2_w, pr.te2_b, silu_in=True, table=pr.label,
+                               idx=y.to(torch.int64).contiguous())
+        else:
+            e = ops.linear_f32(e, pr.te2_w, pr.te2_b, silu_in=True)
+        return ops.linear_f32(e, pr.film_w, pr.film_b, silu_in=True)  # every block's (scale | shift)
+
+    def forward(self, x, timesteps, y=None, skip_layer: Sequence[int] = ()):
+        """x fp32 [N,C,H,W], timesteps [N] (original-process timesteps), y int64 [N] or None."""
+        pr = self._packed or self._prepare()
+        if not x.is_cuda:
+            raise AdmError("UNetModel.forward: x must be a device tensor (no CPU fallback)")
+        skip_ids = set(int(s) for s in skip_layer) if self.plan.dynamic else set()
+        if skip_layer and not self.plan.dynamic:
+            raise TypeError("skip_layer needs a dynamic UNet (use_dynamic_unet=True)")
+        x = x.to(torch.float32).contiguous()
+        with torch.no_grad():
+            film = self._embed(pr, timesteps, y)
+            hs: List[torch.Tensor] = []
+            h = None
+            for seq in self.plan.input_blocks:
+                h = self._run_seq(pr, seq, h, None, film, skip_ids, x_nchw=x)
+                hs.append(h)
+            h = self._run_seq(pr, self.plan.middle_block, h, None, film, skip_ids)
+            for seq in self.plan.output_blocks:
+                h = self._run_seq(pr, seq, h, hs.pop(), film, skip_ids)
+            hd = pr.head
+            aff = ops.gn_affine(h, hd["g"], hd["b"])
+            return ops.conv(h, hd["w"], hd["cb"], self.plan.out_channels, 9, aff=aff, silu=True,
+                            out_f32_nchw=True)
+
+
+Dynamic_UNetModel = UNetModel  # the plan's `dynamic` flag carries the difference

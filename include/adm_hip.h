@@ -1,0 +1,158 @@
+/*
+ * adm_hip.h -- C ABI of libadm_hip.so: the MI355X (gfx950) kernels behind
+ * AutoDiffusion's candidate-evaluation hot path.
+ *
+ * The reference (lilijiangg/AutoDiffusion) is 100 % Python on stock PyTorch
+ * ops: it has NO plugin / FFI interface for this path (SURVEY.md section 2.2,
+ * 8b).  The entry points below are therefore the build's own boundary; each
+ * one cites the reference Python call site it replaces.  A maintainer binds
+ * them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes; every pointer is a DEVICE pointer unless the
+ *     name ends in _host; no torch types, no allocation, no ownership transfer
+ *     (workspaces are caller-owned), no hidden synchronisation;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: 0 = ok, negative = invalid argument (see ADM_E_*),
+ *     positive = hipError_t from the launch; adm_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - activations between kernels are bf16 NHWC ("pixel-major": [N][H][W][C]);
+ *     the UNet's external input / output stay fp32 NCHW as in the reference;
+ *   - safe to call concurrently on different streams / devices.
+ */
+#ifndef ADM_HIP_H
+#define ADM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADM_ABI_VERSION 1
+
+#define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
+#define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
+#define ADM_E_ALIGN    (-3)  /* pointer not 16-byte aligned                    */
+
+typedef uint16_t adm_bf16;   /* raw bfloat16 bits */
+
+int adm_abi_version(void);
+const char* adm_last_error(void);
+
+/* ---------------------------------------------------------------- sampler (K9, A7, A10)
+ * Per-step scalars = the reference's float64 tables cast to float32 exactly as
+ * _extract_into_tensor does (gaussian_diffusion.py:910-923).                           */
+typedef struct adm_step_coefs {
+  float sqrt_recip_ac;    /* sqrt(1/abar_i)            */
+  float sqrt_recipm1_ac;  /* sqrt(1/abar_i - 1)        */
+  float ac;               /* abar_i                    */
+  float ac_prev;          /* abar_{i-1} (1.0 at i = 0) */
+  float coef1, coef2;     /* posterior_mean_coef1/2    */
+  float log_var_lo;       /* posterior_log_variance_clipped_i (LEARNED_RANGE min) or fixed log-variance */
+  float log_var_hi;       /* log(beta_i) (LEARNED_RANGE max); unused for fixed variance   */
+  float fixed_var;        /* fixed variance (FIXED_SMALL/LARGE); unused for learned range */
+  float eta;              /* DDIM eta                  */
+  int32_t nonzero;        /* 0 at i == 0, else 1       */
+  int32_t learned_range;  /* model_out carries 2C channels (eps | v)      */
+  int32_t predict_xstart; /* model output is x0 instead of eps            */
+  int32_t clip_denoised;  /* clamp pred_xstart to [-1, 1]                 */
+} adm_step_coefs;
+
+/* ddim_sample: p_mean_variance + condition_score + eq. 12 update, one pass per pixel.
+ * Replaces gaussian_diffusion.py:258-326, :381-393, :565-584.
+ * x, noise, grad, x_prev, pred_xstart: fp32 [N,C,H,W]; model_out fp32 [N,C or 2C,H,W];
+ * grad / noise / pred_xstart / u8_nhwc may be NULL.  If u8_nhwc != NULL the final image is
+ * also packed as ((s+1)*127.5).clamp(0,255) truncated to uint8, NHWC
+ * (search_imagenet64_classifier_guidance.py:352-354).                                   */
+int adm_ddim_step(const float* x, const float* model_out, const float* grad, const float* noise,
+                  float* x_prev, float* pred_xstart, uint8_t* u8_nhwc,
+                  int n, int c, int h, int w, const adm_step_coefs* coefs_host, void* stream);
+
+/* p_sample: p_mean_variance + condition_mean + ancestral update.
+ * Replaces gaussian_diffusion.py:258-326, :365-369, :430-439.                           */
+int adm_ddpm_step(const float* x, const float* model_out, const float* grad, const float* noise,
+                  float* x_prev, float* pred_xstart, uint8_t* u8_nhwc,
+                  int n, int c, int h, int w, const adm_step_coefs* coefs_host, void* stream);
+
+/* fp32 NCHW in [-1,1] -> uint8 NHWC (truncation), search_...guidance.py:352-354.       */
+int adm_pack_u8_nhwc(const float* x, uint8_t* out, int n, int c, int h, int w, void* stream);
+
+/* ---------------------------------------------------------------- embeddings (K1, A4)
+ * timestep_embedding (nn.py:103-121): t fp32 [N] -> [N, dim] = cos | sin (| 0 if dim odd). */
+int adm_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream);
+
+/* out[n, o] = sum_k act(in[n, k]) * w[o, k] + bias[o] (+ table[idx[n], o]);  fp32.
+ * act = SiLU if silu_in.  Replaces time_embed / label_emb / every ResBlock emb_layers
+ * (unet.py:470-478, 199-205, 245, 648-654); all emb_layers are batched in one call by
+ * concatenating their weights along o.                                                  */
+int adm_linear_f32(const float* in, const float* w, const float* bias, const float* table,
+                   const int64_t* idx, float* out, int n, int k, int o, int silu_in, void* stream);
+
+/* ---------------------------------------------------------------- stem (A5, first conv)
+ * input_blocks.0.0: conv3x3 pad 1 on the fp32 NCHW image -> bf16 NHWC (unet.py:480-483, 656-658). */
+int adm_stem_conv3x3(const float* x_nchw, const float* w /*[Cout,Cin,3,3]*/, const float* bias,
+                     adm_bf16* out_nhwc, int n, int cin, int h, int w_, int cout, void* stream);
+
+/* ---------------------------------------------------------------- GroupNorm (K2/K3 statistics)
+ * GroupNorm32(32, C) statistics over a (virtually concatenated) bf16 NHWC tensor, in fp32 /
+ * fp64 (nn.py:17-19).  Two launches:
+ *   adm_gn_partial : per (image, pixel slab, channel) sum and sum of squares
+ *                    -> partial fp32 [N][slabs][C][2]
+ *   adm_gn_finalize: per (image, channel) affine  y = a*x + b  with
+ *        a = rstd*gamma*(1+scale),  b = (beta - mean*rstd*gamma)*(1+scale) + shift
+ *      (scale/shift = the ResBlock's FiLM pair, unet.py:248-252; NULL -> plain GN).
+ *      film points at scale[0] of image 0; shift = film + C; film_stride = row stride.   */
+int adm_gn_partial(const adm_bf16* in0, int c0, const adm_bf16* in1, int c1, float* partial,
+                   int n, int hw, int slabs, void* stream);
+int adm_gn_finalize(const float* partial, const float* gamma, const float* beta,
+                    const float* film, int film_stride, float* aff_a, float* aff_b,
+                    int n, int c, int hw, int slabs, float eps, void* stream);
+
+/* h_upd / x_upd of an up/down ResBlock (unet.py:190-195, 237-242):
+ * out = resample(act(a*in + b)), act = SiLU when aff_a != NULL, identity copy otherwise.
+ * mode 1 = AvgPool2d(2) (H,W -> H/2,W/2), mode 2 = nearest x2.                          */
+int adm_resample(const adm_bf16* in, const float* aff_a, const float* aff_b, adm_bf16* out,
+                 int n, int h, int w, int c, int mode, void* stream);
+
+/* ---------------------------------------------------------------- fused conv / GEMM (K2,K3,K4,K7,K8)
+ * Implicit-GEMM 3x3 (pad 1) or 1x1 convolution on MFMA, bf16 in / fp32 accumulate:
+ *   out[p, o] = bias[o] + sum_{tap, c} act(a[n,c]*in[p+tap, c] + b[n,c]) * w[o, c, tap] (+ res[p, o])
+ * with the input a virtual concat of (in0 | in1) along channels (th.cat, unet.py:662),
+ * prologue: 0 = raw input, 1 = affine (GroupNorm, attention norm), 2 = affine + SiLU
+ * (in_layers / out_layers / out, unet.py:182-186, 206-222, 612-616); zero padding is applied
+ * AFTER the activation, as in the reference.  res (bf16 NHWC [.., cout]) may be NULL
+ * (skip_connection(x) + h, unet.py:256; x + h, unet.py:305).
+ * out_mode 0: bf16 NHWC; 1: fp32 NCHW (the UNet head, unet.py:664-665).
+ * w_packed comes from adm_pack_conv_weight.  cin (= c0 + c1), c0, c1 % 32 == 0.          */
+typedef struct adm_conv_args {
+  const adm_bf16* in0; const adm_bf16* in1;
+  const adm_bf16* w_packed; const float* bias;
+  const float* aff_a; const float* aff_b;
+  const adm_bf16* res; void* out;
+  int32_t n, h, w, c0, c1, cout;
+  int32_t taps;      /* 9 or 1 */
+  int32_t prologue;  /* 0,1,2  */
+  int32_t out_mode;  /* 0,1    */
+  int32_t variant;   /* tiling variant, 0 = auto (see adm_conv_variants) */
+} adm_conv_args;
+int adm_conv(const adm_conv_args* args_host, void* stream);
+
+/* fp32 [cout, cin, kh, kw] (kh*kw = taps) -> bf16 fragment-ordered image
+ * [cin/32][taps][ceil(cout/16)][64 lanes][8]; out must hold adm_packed_weight_elems().   */
+int64_t adm_packed_weight_elems(int cout, int cin, int taps);
+int adm_pack_conv_weight(const float* w, adm_bf16* out, int cout, int cin, int taps, void* stream);
+
+/* ---------------------------------------------------------------- attention (K5)
+ * QKVAttention / QKVAttentionLegacy (unet.py:361-393 / 328-358) as a flash-style MFMA kernel:
+ * qkv bf16 [N][T][3*H*D] (token-major, the 1x1 qkv conv's NHWC output) -> out bf16 [N][T][H*D];
+ * softmax in fp32 over all T keys, logits scaled by 1/sqrt(D) (= the reference's
+ * ch^-1/4 on q and on k).  new_order 1: channels are [3][H][D]; 0 (legacy): [H][3][D].
+ * D in {32, 64, 128}.                                                                     */
+int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, int d,
+                  int new_order, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADM_HIP_H */

@@ -1,0 +1,240 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (ctypes -> libadm_hip.so).
+
+Each HIP kernel is compared with the CPU oracle (or a plain PyTorch-CPU fp32
+statement of the same op) on identical seeded inputs.  Tolerances:
+  * fp32 elementwise kernels (sampler, embeddings): 1e-5 relative -- they compute
+    in fp32 exactly as the reference does;
+  * bf16 MFMA kernels: inputs / weights are rounded to bf16 on BOTH sides, the
+    accumulation is fp32, so the remaining difference is summation order plus the
+    final bf16 rounding of the output: |err| <= 1e-2 * max|ref| elementwise and
+    <= 4e-3 relative in Frobenius norm.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from autodiffusion_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def nhwc_dev(x):  # fp32 NCHW cpu -> bf16 NHWC device
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def nchw_cpu(y):  # bf16 NHWC device -> fp32 NCHW cpu
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def assert_close_bf16(got, ref, what=""):
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    fro = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+    assert err <= 1e-2 * scale and fro <= 4e-3, f"{what}: max err {err:.4g} (scale {scale:.4g}), fro {fro:.4g}"
+
+
+# ------------------------------------------------------------------ sampler (K9)
+def _coefs(d, i, eta=0.0, clip=True):
+    from autodiffusion_amd.sampler import step_coefs
+    return step_coefs(d.tables, i, learned_range=(d.var_type == "learned_range"),
+                      fixed=("large" if d.var_type == "fixed_large" else "small"),
+                      predict_xstart=d.predict_xstart, clip_denoised=clip, eta=eta)
+
+
+@pytest.mark.parametrize("learn_sigma", [True, False])
+def test_sampler_steps_match_oracle(ops, learn_sigma):
+    from oracle import sampler as osm, schedule
+    d = schedule.OracleDiffusion(steps=1000, noise_schedule="cosine", learn_sigma=learn_sigma).reset([153, 424, 926, 690])
+    n, c, h, w = 3, 3, 16, 16
+    x, g, nz = rnd((n, c, h, w), 1), rnd((n, c, h, w), 2, 0.3), rnd((n, c, h, w), 3)
+    mo = rnd((n, 2 * c if learn_sigma else c, h, w), 4)
+    for i in (3, 1, 0):
+        for grad in (None, g):
+            for eta in (0.0, 0.7):
+                ref = osm.ddim_step(d, mo, x, i, grad, nz, eta)
+                xp, x0, _ = ops.sampler_step("ddim", x.to(DEV), mo.to(DEV), _coefs(d, i, eta),
+                                             None if grad is None else grad.to(DEV), nz.to(DEV), want_xstart=True)
+                torch.testing.assert_close(xp.cpu(), ref["sample"], rtol=1e-5, atol=1e-5)
+                torch.testing.assert_close(x0.cpu(), ref["pred_xstart"], rtol=1e-5, atol=1e-5)
+            ref = osm.ddpm_step(d, mo, x, i, grad, nz)
+            xp, x0, u8 = ops.sampler_step("ddpm", x.to(DEV), mo.to(DEV), _coefs(d, i),
+                                          None if grad is None else grad.to(DEV), nz.to(DEV),
+                                          want_xstart=True, want_u8=True)
+            torch.testing.assert_close(xp.cpu(), ref["sample"], rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(x0.cpu(), ref["pred_xstart"], rtol=1e-5, atol=1e-5)
+            assert torch.equal(u8.cpu(), osm.pack_uint8_nhwc(xp.cpu()))
+
+
+def test_pack_u8_bit_exact_and_odd_sizes(ops):
+    from oracle import sampler as osm
+    for shape in ((2, 3, 8, 8), (1, 3, 5, 7), (3, 1, 64, 64)):
+        x = rnd(shape, 5, 1.2)
+        x.view(-1)[:4] = torch.tensor([-1.0, 1.0, 0.99999, -3.0])
+        assert torch.equal(ops.pack_u8_nhwc(x.to(DEV)).cpu(), osm.pack_uint8_nhwc(x))
+
+
+def test_step_requires_noise_when_used(ops):
+    from oracle import schedule
+    from autodiffusion_amd._lib import AdmError
+    d = schedule.OracleDiffusion(steps=1000, noise_schedule="linear", learn_sigma=True).reset([10, 500])
+    x = rnd((1, 3, 8, 8), 1).to(DEV)
+    mo = rnd((1, 6, 8, 8), 2).to(DEV)
+    with pytest.raises(AdmError):
+        ops.sampler_step("ddpm", x, mo, _coefs(d, 1), None, None)
+    ops.sampler_step("ddpm", x, mo, _coefs(d, 0), None, None)  # i == 0 adds no noise
+
+
+# ------------------------------------------------------------------ embeddings (K1)
+def test_timestep_embedding(ops):
+    from oracle import nets
+    t = torch.tensor([0, 1, 250, 999, 37])
+    for dim in (192, 32, 33, 128):
+        got = ops.timestep_embedding(t.to(DEV), dim).cpu()
+        torch.testing.assert_close(got, nets.sinusoid_embedding(t, dim), rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("n,k,o", [(2, 128, 64), (5, 768, 1000), (256, 768, 1536), (3, 32, 128)])
+def test_linear_f32(ops, n, k, o):
+    x, w, b = rnd((n, k), 1), rnd((o, k), 2, k ** -0.5), rnd((o,), 3, 0.1)
+    tab, idx = rnd((10, o), 4), torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(5))
+    got = ops.linear_f32(x.to(DEV), w.to(DEV), b.to(DEV), silu_in=True, table=tab.to(DEV), idx=idx.to(DEV)).cpu()
+    ref = F.linear(F.silu(x), w, b) + tab[idx]
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    got = ops.linear_f32(x.to(DEV), w.to(DEV), None).cpu()
+    torch.testing.assert_close(got, F.linear(x, w), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ stem / GN / resample
+def test_stem_conv(ops):
+    x, w, b = rnd((3, 3, 32, 32), 1), rnd((64, 3, 3, 3), 2, 0.2), rnd((64,), 3, 0.1)
+    got = nchw_cpu(ops.stem_conv3x3(x.to(DEV), w.to(DEV), b.to(DEV)))
+    assert_close_bf16(got, F.conv2d(x, w, b, padding=1), "stem")
+
+
+@pytest.mark.parametrize("c0,c1,hw", [(64, 0, 8), (192, 0, 64), (768, 576, 8), (32, 32, 16), (1536, 0, 8)])
+def test_gn_affine_matches_group_norm(ops, c0, c1, hw):
+    n = 3
+    c = c0 + c1
+    x = bf(rnd((n, c, hw, hw), 1, 1.5) + 0.3)
+    gamma, beta = 1 + 0.2 * rnd((c,), 2), 0.1 * rnd((c,), 3)
+    film = rnd((n, 2 * c + 5), 4, 0.3)  # wider row: exercises film_stride
+    x0 = nhwc_dev(x[:, :c0])
+    x1 = nhwc_dev(x[:, c0:]) if c1 else None
+    filmd = film.to(DEV)
+    a, b = ops.gn_affine(x0, gamma.to(DEV), beta.to(DEV), x1, film=filmd, film_stride=film.shape[1])
+    got = a.cpu()[:, :, None, None] * x + b.cpu()[:, :, None, None]
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5) * (1 + film[:, :c, None, None]) + film[:, c:2 * c, None, None]
+    torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4)
+    a, b = ops.gn_affine(x0, gamma.to(DEV), beta.to(DEV), x1)
+    got = a.cpu()[:, :, None, None] * x + b.cpu()[:, :, None, None]
+    torch.testing.assert_close(got, F.group_norm(x, 32, gamma, beta, eps=1e-5), rtol=2e-4, atol=2e-4)
+
+
+def test_resample(ops):
+    x = bf(rnd((2, 64, 16, 16), 1))
+    a, b = 1 + 0.1 * rnd((2, 64), 2), 0.1 * rnd((2, 64), 3)
+    act = F.silu(a[:, :, None, None] * x + b[:, :, None, None])
+    xd = nhwc_dev(x)
+    aff = (a.to(DEV), b.to(DEV))
+    assert_close_bf16(nchw_cpu(ops.resample(xd, "down")), F.avg_pool2d(x, 2), "down raw")
+    assert_close_bf16(nchw_cpu(ops.resample(xd, "up")), F.interpolate(x, scale_factor=2, mode="nearest"), "up raw")
+    assert_close_bf16(nchw_cpu(ops.resample(xd, "down", aff)), F.avg_pool2d(act, 2), "down act")
+    assert_close_bf16(nchw_cpu(ops.resample(xd, "up", aff)), F.interpolate(act, scale_factor=2, mode="nearest"), "up act")
+
+
+# ------------------------------------------------------------------ conv (K2/K3/K4/K7/K8)
+CONV_CASES = [
+    # n, hw, c0, c1, cout, taps, prologue(0 raw,1 affine,2 affine+silu), res, f32_nchw, variant
+    (2, 16, 32, 0, 64, 9, 2, False, False, 0),
+    (3, 8, 64, 0, 96, 9, 2, True, False, 0),     # TI=4 with a ragged last tile (3 images)
+    (1, 32, 64, 32, 128, 9, 2, True, False, 0),  # virtual concat
+    (2, 64, 32, 0, 6, 9, 2, False, True, 0),     # output head, fp32 NCHW
+    (2, 16, 192, 0, 192, 9, 0, False, False, 0),
+    (2, 16, 64, 0, 192, 1, 1, False, False, 0),  # qkv projection (GN, no SiLU)
+    (2, 8, 96, 0, 96, 1, 0, True, False, 0),     # proj_out + residual
+    (5, 8, 64, 64, 64, 1, 0, False, False, 0),   # skip 1x1 on a concat
+    (1, 16, 64, 0, 256, 9, 2, False, False, 1),
+    (1, 16, 64, 0, 256, 9, 2, False, False, 2),
+    (1, 16, 64, 0, 256, 9, 2, False, False, 4),
+    (2, 32, 96, 0, 16, 9, 2, False, False, 3),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fused(ops, case):
+    n, hw, c0, c1, cout, taps, prologue, use_res, f32, variant = case
+    cin = c0 + c1
+    k = 3 if taps == 9 else 1
+    x = bf(rnd((n, cin, hw, hw), 1))
+    w = rnd((cout, cin, k, k), 2, (cin * taps) ** -0.5)
+    b = rnd((cout,), 3, 0.1)
+    a_, b_ = 1 + 0.2 * rnd((n, cin), 4), 0.2 * rnd((n, cin), 5)
+    res = bf(rnd((n, cout, hw, hw), 6))
+    h = x
+    if prologue:
+        h = a_[:, :, None, None] * x + b_[:, :, None, None]
+        if prologue == 2:
+            h = F.silu(h)
+    ref = F.conv2d(bf(h), bf(w), b, padding=k // 2)
+    if use_res:
+        ref = ref + res
+    wp = ops.pack_conv_weight(w.to(DEV))
+    got = ops.conv(nhwc_dev(x[:, :c0]), wp, b.to(DEV), cout, taps,
+                   x1=nhwc_dev(x[:, c0:]) if c1 else None,
+                   aff=(a_.to(DEV), b_.to(DEV)) if prologue else None, silu=(prologue == 2),
+                   res=nhwc_dev(res) if use_res else None, out_f32_nchw=f32, variant=variant)
+    got = got.cpu() if f32 else nchw_cpu(got)
+    assert_close_bf16(got, ref, f"conv {case}")
+
+
+def test_conv_rejects_bad_shapes(ops):
+    from autodiffusion_amd._lib import AdmError
+    x = torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=DEV)
+    wp = ops.pack_conv_weight(torch.zeros((32, 32, 3, 3), device=DEV))
+    with pytest.raises(AdmError):
+        ops.conv(x, wp, torch.zeros(32, device=DEV), 32, 9)  # 4x4 map: below the halo tile
+    with pytest.raises(AdmError):
+        ops.pack_conv_weight(torch.zeros((32, 24, 3, 3), device=DEV))  # cin % 32 != 0
+
+
+# ------------------------------------------------------------------ attention (K5)
+@pytest.mark.parametrize("n,heads,d,t", [(2, 2, 32, 64), (2, 1, 64, 256), (1, 6, 64, 1024), (3, 2, 32, 16),
+                                         (1, 2, 64, 80), (2, 4, 128, 256)])
+@pytest.mark.parametrize("new_order", [True, False])
+def test_attention_matches_oracle(ops, n, heads, d, t, new_order):
+    from oracle import nets
+    qkv = bf(rnd((n, 3 * heads * d, t), 7))
+    ref = nets.qkv_attention(qkv, heads, new_order)  # [n, H*D, t]
+    got = ops.attention(qkv.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV), heads, new_order)
+    got = got.float().cpu().permute(0, 2, 1)
+    assert_close_bf16(got, ref, f"attention {n, heads, d, t, new_order}")
+
+
+def test_attention_softmax_is_stable_for_large_logits(ops):
+    from oracle import nets
+    qkv = bf(rnd((1, 3 * 64, 128), 8, 6.0))  # logits ~ +-100: needs the running-max rescale
+    ref = nets.qkv_attention(qkv, 1, True)
+    got = ops.attention(qkv.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV), 1, True)
+    got = got.float().cpu().permute(0, 2, 1)
+    assert torch.isfinite(got).all()
+    assert_close_bf16(got, ref, "attention large logits")
