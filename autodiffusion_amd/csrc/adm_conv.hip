@@ -382,7 +382,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     else if (a->cout <= 64) variant = 4;
     else {
       const int w128 = ((a->cout + 127) / 128) * 128, w96 = ((a->cout + 95) / 96) * 96;
-      variant = (w96 < w128) ? 2 : 1;
+      variant = (w96 <= w128) ? 2 : 1;
     }
   }
   switch (variant) {

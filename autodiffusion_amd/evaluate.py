@@ -1,0 +1,85 @@
+"""Candidate evaluation: sample an image batch with a searched schedule (and layer-skip mask).
+
+The device-side half of ``EvolutionSearcher.get_cand_fid`` (reference
+search_imagenet64_classifier_guidance.py:308-366; dict candidates with per-step skip lists:
+search_dynamic_unet_imagenet64_classifier_guidance_progressive.py:369-445; unconditional:
+search_uncondition_model.py:312-368): reset_diffusion(cand) -> sample loop -> uint8 NHWC batch.
+Differences from the reference, by design: images stay on the producing GPU
+(no per-batch all_gather / D2H), and every batch is seeded per (seed) so results do not depend on
+how batches are sharded over ranks.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional, Sequence, Union
+
+import torch
+
+from .schedule import apply_candidate
+
+NUM_CLASSES = 1000
+
+
+class CandidateEvaluator:
+    def __init__(self, model, base_diffusion, classifier=None, *, image_size: int, use_ddim: bool = True,
+                 clip_denoised: bool = True, class_cond: bool = True, classifier_scale: float = 1.0,
+                 device=None):
+        self.model = model
+        self.classifier = classifier
+        self.base_diffusion = base_diffusion
+        self.active_diffusion = copy.deepcopy(base_diffusion)
+        self.image_size = image_size
+        self.use_ddim = use_ddim
+        self.clip_denoised = clip_denoised
+        self.class_cond = class_cond
+        self.classifier_scale = classifier_scale
+        self.device = device if device is not None else model.device
+        self.skip_layers = None
+
+    def set_candidate(self, cand: Union[Sequence[int], dict]):
+        """reset_diffusion(cand); dict candidates also carry one skip-layer list per step."""
+        if isinstance(cand, dict):
+            assert len(cand["timesteps"]) == len(cand["skip_layers"])
+            self.skip_layers = [list(s) for s in cand["skip_layers"]]
+            steps = cand["timesteps"]
+        else:
+            self.skip_layers = None
+            steps = cand
+        apply_candidate(self.active_diffusion, self.base_diffusion, steps)
+        return self
+
+    # closures with the reference's calling convention ------------------------------------------
+    def _model_fn(self, x, t, y=None, skip_layers=None):
+        yy = y if self.class_cond else None
+        if skip_layers is not None:
+            # the search script indexes by position in the ASCENDING timestep_map
+            sl = skip_layers[self.active_diffusion.timestep_map.index(int(t[0]))]
+            return self.model(x, t, yy, skip_layer=sl)
+        return self.model(x, t, yy)
+
+    def _cond_fn(self, x, t, y=None, skip_layers=None):
+        assert y is not None
+        return self.classifier.log_prob_grad(x, t, y, self.classifier_scale)
+
+    def sample_batch(self, batch_size: int, seed: Optional[int] = None, return_float: bool = False):
+        """-> uint8 NHWC [B, H, W, 3] on the device (and the fp32 sample if return_float)."""
+        dev = self.device
+        gen = None
+        if seed is not None:
+            gen = torch.Generator(device=dev).manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+        classes = torch.randint(low=0, high=NUM_CLASSES, size=(batch_size,), device=dev, generator=gen)
+        shape = (batch_size, 3, self.image_size, self.image_size)
+        x_T = torch.randn(*shape, device=dev, generator=gen)
+        d = self.active_diffusion
+        d.generator = gen
+        kwargs = {"y": classes}
+        if self.skip_layers is not None:
+            kwargs["skip_layers"] = self.skip_layers
+        fn = d.ddim_sample_loop if self.use_ddim else d.p_sample_loop
+        sample = fn(self._model_fn, shape, noise=x_T, clip_denoised=self.clip_denoised, model_kwargs=kwargs,
+                    cond_fn=self._cond_fn if self.classifier is not None else None, device=dev)
+        u8 = d.last_uint8_nhwc
+        self.last_classes = classes
+        if return_float:
+            return u8, sample
+        return u8

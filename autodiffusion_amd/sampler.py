@@ -69,6 +69,8 @@ class SpacedDiffusion:
         base_ac = np.cumprod(1.0 - np.array(betas, dtype=np.float64), axis=0)
         new_betas, self.timestep_map = subset_betas(base_ac, self.use_timesteps)
         install_tables(self, new_betas, allow_single_step=False)
+        self.generator = None         # optional torch.Generator for the per-step noise draws
+        self.last_uint8_nhwc = None   # uint8 NHWC pack of the last finished loop (fused into the final step)
         if model_mean_type == ModelMeanType.PREVIOUS_X:
             raise NotImplementedError("ModelMeanType.PREVIOUS_X is not produced by any reference factory")
         if model_var_type == ModelVarType.LEARNED:
@@ -91,15 +93,17 @@ class SpacedDiffusion:
         return new_ts
 
     def _step(self, kind, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
-              want_u8=False):
+              want_u8=False, index=None):
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn breaks the fused per-pixel update; no reference script uses it")
         if model_kwargs is None:
             model_kwargs = {}
-        idx = t.tolist()
-        if len(set(idx)) != 1:
-            raise NotImplementedError("per-sample step indices: the sample loops always pass one index per batch")
-        i = int(idx[0])
+        if index is None:  # direct p_sample / ddim_sample calls: read the index back from the tensor
+            idx = t.tolist()
+            if len(set(idx)) != 1:
+                raise NotImplementedError("per-sample step indices: the sample loops always pass one index per batch")
+            index = int(idx[0])
+        i = index
         ts = self._mapped(t)
         x = x.contiguous()
         model_out = model(x, ts, **model_kwargs)
@@ -108,7 +112,11 @@ class SpacedDiffusion:
         grad = None
         if cond_fn is not None:
             grad = cond_fn(x, ts, **model_kwargs).float().contiguous()
-        noise = torch.randn_like(x)  # drawn every step, as the reference does (RNG stream parity)
+        # drawn every step, as the reference does (keeps the RNG stream aligned with it)
+        if self.generator is not None:
+            noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=self.generator)
+        else:
+            noise = torch.randn_like(x)
         sample, x0, u8 = ops.sampler_step(kind, x, model_out.contiguous(), self._coefs(i, clip_denoised, eta),
                                           grad, noise, want_xstart=True, want_u8=want_u8)
         out = {"sample": sample, "pred_xstart": x0}
@@ -140,7 +148,7 @@ class SpacedDiffusion:
             t = torch.tensor([i] * shape[0], device=device)
             with torch.no_grad():
                 out = self._step(kind, model, img, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta,
-                                 want_u8=(i == 0))
+                                 want_u8=(i == 0), index=i)
             yield out
             img = out["sample"]
 

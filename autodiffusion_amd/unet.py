@@ -110,6 +110,21 @@ class HipModule:
     def requires_grad_(self, flag=False):
         return self
 
+    def randomize_(self, seed: int = 1234, std_scale: float = 1.0):
+        """Synthetic weights for benchmarks (no checkpoint is reachable offline): every tensor,
+        including the zero-initialised ones, ~ N(0, std_scale^2 / fan_in); GroupNorm gamma = 1."""
+        for i, (k, v) in enumerate(self._params.items()):
+            g = torch.Generator(device=v.device).manual_seed(seed + i)
+            if v.dim() >= 2:
+                fan_in = v[0].numel()
+                self._params[k] = torch.randn(v.shape, generator=g, device=v.device) * (std_scale / fan_in ** 0.5)
+            elif k.rsplit(".", 1)[-1] == "weight":
+                self._params[k] = torch.ones_like(v)
+            else:
+                self._params[k] = torch.randn(v.shape, generator=g, device=v.device) * 0.02
+        self._packed = None
+        return self
+
     def convert_to_fp16(self):
         """Reference API (unet.py:618-624).  The HIP torso always computes in bf16 with fp32
         accumulate/GroupNorm/softmax; this only records the reference's dtype attribute."""

@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the candidate-evaluation hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch: B images sampled with the searched 4-step
+DDIM schedule [153, 424, 926, 690] through the ADM-G ImageNet-64 UNet (classifier-guided when
+--workload guided), ending in the fused uint8 NHWC pack.  Synthetic data: x_T ~ N(0,1), labels
+~ U{0..999}, random-init weights of the real architecture (no checkpoint is reachable offline).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload guided|unguided]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...` (one rank per GPU, RCCL): the batch shards by image with no data-path collective
+(weak scaling); timing is barrier + synchronize bracketed, MAX over ranks.  Rank 0 prints ONE JSON
+line with the metric, the dominant kernel's roofline (HIP events on the launch stream) and the CPU
+oracle baseline timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+SCHEDULE = [153, 424, 926, 690]            # reference scripts/classifier_sample_generate_image.py:164
+GFLOP_UNET = 219.64                        # per image per UNet eval
+GFLOP_GUIDE = 93.85                        # classifier fwd + backward-data per image per step
+PEAK_BF16_TFLOPS = 2500.0                  # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def adm64_flags(class_cond=True, dynamic=False):
+    from autodiffusion_amd.script_util import model_and_diffusion_defaults
+    d = model_and_diffusion_defaults()
+    d.update(attention_resolutions="32,16,8", class_cond=class_cond, diffusion_steps=1000, dropout=0.1,
+             image_size=64, learn_sigma=True, noise_schedule="cosine", num_channels=192,
+             num_head_channels=64, num_res_blocks=3, resblock_updown=True, use_new_attention_order=True,
+             use_fp16=True, use_scale_shift_norm=True, use_dynamic_unet=dynamic)
+    return d
+
+
+def cpu_baseline(sample_batch=4):
+    """The CPU oracle on BASELINE config 1 (ADM-64 unconditional, ddim4, fp32) on this host's cores."""
+    import numpy as np
+    from autodiffusion_amd.arch import build_unet_plan
+    from oracle import nets, sampler as osm, schedule as osch
+    plan = build_unet_plan(64, 3, 192, 6, 3, (2, 4, 8), (1, 2, 3, 4), num_classes=None, num_head_channels=64,
+                           use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True)
+    g = torch.Generator().manual_seed(1234)
+    P = {}
+    for k, shp in plan.param_shapes().items():
+        if len(shp) >= 2:
+            P[k] = torch.randn(shp, generator=g) * (1.0 / float(np.prod(shp[1:])) ** 0.5)
+        elif k.endswith("weight"):
+            P[k] = torch.ones(shp)
+        else:
+            P[k] = torch.zeros(shp)
+    cores = torch.get_num_threads()
+    d = osch.OracleDiffusion(steps=1000, noise_schedule="cosine", learn_sigma=True, timestep_respacing="ddim4")
+    x = torch.randn(sample_batch, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    fn = lambda xx, t: nets.unet_forward(P, plan, xx, t)  # noqa: E731
+    with torch.no_grad():
+        fn(x[:1], torch.zeros(1, dtype=torch.int64))  # warm-up
+    t0 = time.time()
+    osm.sample_loop(d, fn, x, use_ddim=True)
+    dt = time.time() - t0
+    return {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement), ADM-64 unconditional ddim4, one batch of "
+                      f"{sample_batch} images = {4 * sample_batch} UNet evals, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--workload", default="auto", choices=["auto", "guided", "unguided"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+
+    from autodiffusion_amd import ops
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    from autodiffusion_amd.script_util import (args_to_dict, classifier_defaults, create_classifier,
+                                               create_model_and_diffusion, model_and_diffusion_defaults)
+
+    guided = args.workload in ("auto", "guided")
+    flags = adm64_flags(class_cond=True)
+    model, diffusion = create_model_and_diffusion(**args_to_dict(argparse.Namespace(**flags),
+                                                                 model_and_diffusion_defaults().keys()))
+    model.to(dev).randomize_(1234).convert_to_fp16()
+    classifier = None
+    if guided:
+        try:
+            cf = classifier_defaults()
+            cf.update(image_size=64, classifier_depth=4)
+            classifier = create_classifier(**cf)
+            classifier.to(dev).randomize_(4321)
+            if not hasattr(classifier, "log_prob_grad"):
+                raise NotImplementedError
+        except (ImportError, NotImplementedError):
+            if args.workload == "guided":
+                raise
+            classifier, guided = None, False
+
+    ev = CandidateEvaluator(model, diffusion, classifier=classifier, image_size=64, use_ddim=True,
+                            classifier_scale=1.0, class_cond=True, device=dev)
+    ev.set_candidate(SCHEDULE)
+    B = args.batch
+
+    def one_step(step_idx):
+        # deterministic, layout-independent seeding per (step, rank)
+        return ev.sample_batch(B, seed=(1000003 * step_idx + rank))
+
+    for w in range(args.warmup):
+        one_step(-1 - w)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_kernel_events:
+        ops.CONV_PROFILE = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(s)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    roof = None
+    if ops.CONV_PROFILE is not None:
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        dom = [p for p in prof if p[3] == 2]  # conv_kernel<2,2,8,3,2>: the 256x96 tile, every ADM-64 torso conv
+        if dom:
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in dom)
+            fl = sum(f for _, _, f, _ in dom)
+            achieved = fl / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_kernel<2,2,8,3,2> (fused GN+SiLU+conv, 256x96 tile)",
+                    "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": len(dom), "avg_launch_us": round(ms * 1e3 / len(dom), 2),
+                    "avg_launch_gflop": round(fl / len(dom) / 1e9, 3),
+                    "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        value = imgs / elapsed
+        gflop_img = len(SCHEDULE) * (GFLOP_UNET + (GFLOP_GUIDE if guided else 0.0))
+        out = {
+            "metric": "images/sec (node), ADM-G ImageNet-64 4-step DDIM",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (x_T ~ N(0,1), y ~ U{0..999}, random-init weights of the ADM-G-64 architecture)",
+            "config": {"workload": ("ADM-G ImageNet-64 classifier-guided" if guided else
+                                    "ADM ImageNet-64 class-conditional, UNGUIDED (classifier guidance not in this run)")
+                       + f", searched 4-step DDIM {SCHEDULE}, batch={B} per GPU, bf16",
+                       "global_batch": world * B, "image_size": 64, "sampler_steps": len(SCHEDULE),
+                       "parallelism": f"dp{world} (image-sharded, no data-path collective)"},
+            "model_tflops": round(value * gflop_img / 1e3, 1),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
