@@ -52,12 +52,24 @@ SIGNATURES = {
     "adm_linear_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "adm_stem_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_gn_partial": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
-    "adm_gn_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "adm_gn_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "adm_resample": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_conv": (_I, [C.POINTER(ConvArgs), _P]),
     "adm_packed_weight_elems": (C.c_int64, [_I, _I, _I]),
     "adm_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "adm_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_attention_lse": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_gn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "adm_gn_bwd_finalize": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "adm_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "adm_grad_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_logsoftmax_grad": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "adm_pool_prep": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "adm_pool_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_pool_attn_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_pool_prep_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "adm_pack_conv_weight_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

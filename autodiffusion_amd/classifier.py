@@ -1,0 +1,135 @@
+"""Noisy-image classifier (EncoderUNetModel) forward and its input gradient on HIP kernels.
+
+Mirror of the reference classifier interface (``EncoderUNetModel`` guided_diffusion/unet.py:685-896,
+``AttentionPool2d`` :22-51, built by ``create_classifier`` script_util.py:257-295) plus the one
+quantity candidate evaluation needs from it -- the guidance gradient of ``cond_fn``
+(search_imagenet64_classifier_guidance.py:319-326):
+
+    log_prob_grad(x, t, y, s) = s * d/dx sum_n log_softmax(f(x, t))[n, y_n]
+
+The reference runs torch.autograd; here the backward network is explicit (data gradients only):
+every conv's backward-data is the same fused MFMA conv kernel with transposed, tap-flipped weights;
+GroupNorm(+FiLM)+SiLU, attention and the attention pool have dedicated backward kernels
+(csrc/adm_backward.hip, csrc/adm_attention_bwd.hip).  Activations and gradients between kernels are
+bf16 NHWC; accumulation, GroupNorm statistics, softmax and the logits are fp32.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import AdmError
+from .arch import AttnPoolSpec, UNetPlan
+from .unet import AdmNet
+
+
+class EncoderUNetModel(AdmNet):
+    with_backward = True
+
+    def __init__(self, plan: UNetPlan, use_fp16: bool = False):
+        if not plan.encoder_only or not isinstance(plan.head, AttnPoolSpec):
+            raise ValueError("EncoderUNetModel needs an encoder plan with the attention pool head")
+        super().__init__(plan, use_fp16)
+
+    # ------------------------------------------------------------------ head weights
+    def _prepare_head(self, pr, P, f32):
+        h: AttnPoolSpec = self.plan.head
+        p = h.prefix
+        wc = f32(f"{p}.2.c_proj.weight").reshape(h.out_dim, h.channels).contiguous()
+        pr.head = dict(
+            g=f32(f"{p}.0.weight"), b=f32(f"{p}.0.bias"), pos=f32(f"{p}.2.positional_embedding"),
+            wqkv=ops.pack_conv_weight(P[f"{p}.2.qkv_proj.weight"]), bqkv=f32(f"{p}.2.qkv_proj.bias"),
+            wqkv_bwd=ops.pack_conv_weight_bwd(P[f"{p}.2.qkv_proj.weight"]),
+            wc=wc, bc=f32(f"{p}.2.c_proj.bias"), wc_t=wc.t().contiguous(),
+        )
+        pr.zero_bias = torch.zeros(max(pr.zero_bias.numel(), 3 * h.channels), dtype=torch.float32,
+                                   device=pr.zero_bias.device)
+
+    # ------------------------------------------------------------------ forward
+    def _features(self, pr, x, timesteps, tape):
+        film = self._embed(pr, timesteps, None)
+        h = None
+        for seq in self.plan.input_blocks:
+            h = self._run_seq(pr, seq, h, None, film, (), x_nchw=x, tape=tape)
+        return self._run_seq(pr, self.plan.middle_block, h, None, film, (), tape=tape)
+
+    def _head_forward(self, pr, h, tape):
+        hs: AttnPoolSpec = self.plan.head
+        hd = pr.head
+        n, hh, ww, c = h.shape
+        if hh * ww != 64:
+            raise AdmError(f"attention pool: {hh}x{ww} final map unsupported (reference classifiers end at 8x8)")
+        t = hh * ww + 1
+        tpad = 128
+        if tape is not None:
+            a_, b_, st = ops.gn_affine(h, hd["g"], hd["b"], want_stats=True)
+        else:
+            a_, b_ = ops.gn_affine(h, hd["g"], hd["b"])
+            st = None
+        tok = ops.pool_prep(h, (a_, b_), hd["pos"], tpad)
+        # qkv_proj as a 1x1 conv over the padded token rows, viewed as 8x8 maps (rows are independent)
+        qkv = ops.conv(tok.view(n * tpad // 64, 8, 8, c), hd["wqkv"], hd["bqkv"], 3 * c, 1)
+        qkv = qkv.view(n, tpad, 3 * c)
+        a0, wts = ops.pool_attn_fwd(qkv, t, hs.num_heads)
+        logits = ops.linear_f32(a0, hd["wc"], hd["bc"])
+        if tape is not None:
+            tape.append(("pool", hs, dict(h=h, aff=(a_, b_), st=st, qkv=qkv, wts=wts, t=t, tpad=tpad)))
+        return logits
+
+    def forward(self, x, timesteps):
+        """x fp32 [N,3,H,W], timesteps [N] -> logits fp32 [N, 1000]."""
+        pr = self._packed or self._prepare()
+        if not x.is_cuda:
+            raise AdmError("EncoderUNetModel.forward: x must be a device tensor (no CPU fallback)")
+        with torch.no_grad():
+            x = x.to(torch.float32).contiguous()
+            return self._head_forward(pr, self._features(pr, x, timesteps, None), None)
+
+    # ------------------------------------------------------------------ backward-data
+    def _bwd_conv(self, pr, dy, w_bwd, cout, taps):
+        return ops.conv(dy, w_bwd, pr.zero_bias, cout, taps)
+
+    def log_prob_grad(self, x, timesteps, y, scale: float = 1.0, return_logits: bool = False):
+        """scale * grad_x sum_n log_softmax(f(x,t))[n, y_n]; fp32 [N,3,H,W]."""
+        pr = self._packed or self._prepare()
+        if not x.is_cuda:
+            raise AdmError("EncoderUNetModel.log_prob_grad: x must be a device tensor (no CPU fallback)")
+        with torch.no_grad():
+            x = x.detach().to(torch.float32).contiguous()
+            tape = []
+            logits = self._head_forward(pr, self._features(pr, x, timesteps, tape), tape)
+            g = None
+            for kind, s, t in reversed(tape):
+                if kind == "pool":
+                    hd = pr.head
+                    n, hh, ww, c = t["h"].shape
+                    dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale)
+                    da0 = ops.linear_f32(dl, hd["wc_t"], None)
+                    dqkv = ops.pool_attn_bwd(t["qkv"], t["wts"], da0, t["t"], s.num_heads)
+                    dtok = self._bwd_conv(pr, dqkv.view(n * t["tpad"] // 64, 8, 8, 3 * c), hd["wqkv_bwd"], c, 1)
+                    dact = ops.pool_prep_bwd(dtok.view(n, t["tpad"], c), hh, ww)
+                    g = ops.gn_bwd(t["h"], dact, t["aff"], t["st"], silu=True)
+                elif kind == "attn":
+                    d = pr.blocks[s.prefix]
+                    n, hh, ww, c = t["x"].shape
+                    da = self._bwd_conv(pr, g, d["wproj_bwd"], c, 1)
+                    dqkv = ops.attention_bwd(t["qkv"].view(n, hh * ww, 3 * c), t["a"], da.view(n, hh * ww, c),
+                                             t["lse"], s.num_heads, s.new_order)
+                    dgn = self._bwd_conv(pr, dqkv.view(n, hh, ww, 3 * c), d["wqkv_bwd"], c, 1)
+                    g = ops.gn_bwd(t["x"], dgn, t["aff"], t["st"], silu=False, add=g)
+                elif kind == "res":
+                    d = pr.blocks[s.prefix]
+                    d_act2 = self._bwd_conv(pr, g, d["w2_bwd"], s.cout, 9)
+                    dh1 = ops.gn_bwd(t["h1"], d_act2, t["aff2"], t["st2"], silu=True)
+                    d_in = self._bwd_conv(pr, dh1, d["w1_bwd"], s.cin, 9)
+                    if s.down:
+                        g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, dy_half=True, add=g, add_half=True)
+                    elif s.up:
+                        raise NotImplementedError("up-sampling ResBlocks do not occur in the encoder")
+                    else:
+                        dskip = self._bwd_conv(pr, g, d["ws_bwd"], s.cin, 1) if s.has_skip_conv else g
+                        g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, add=dskip)
+                elif kind == "stem":
+                    d = pr.blocks[s.prefix]
+                    g = ops.conv(g, d["w_bwd"], pr.zero_bias, s.cin, 9, out_f32_nchw=True)
+            return (g, logits) if return_logits else g

@@ -23,7 +23,7 @@ constexpr int QB = 128;       // queries per block
 constexpr int PADE = 8;       // bf16 elements of row padding
 
 struct AttnK {
-  const uint16_t* qkv; uint16_t* out;
+  const uint16_t* qkv; uint16_t* out; float* lse;
   int T, heads, C3, C;
   int q_off, k_off, v_off, head_stride;
   float scale_log2;  // log2(e) / sqrt(D)
@@ -174,6 +174,8 @@ attn_kernel(const AttnK p) {
     const float inv = 1.0f / l;
     const int q = qbase + qt * 16 + lc;
     if (q >= p.T) continue;
+    // log2-domain log-sum-exp of the scaled logits: P = exp2(s * scale_log2 - lse)
+    if (p.lse && lq == 0) p.lse[((long long)n * p.heads + hd) * p.T + q] = m_run[qt] * p.scale_log2 + log2f(l);
     uint16_t* orow = p.out + ((long long)n * p.T + q) * p.C + hd * D;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -188,15 +190,23 @@ attn_kernel(const AttnK p) {
 
 }  // namespace
 
+extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int t, int heads, int d,
+                                 int new_order, void* stream);
+
 extern "C" int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, int d, int new_order,
                              void* stream) {
+  return adm_attention_lse(qkv, out, nullptr, n, t, heads, d, new_order, stream);
+}
+
+extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int t, int heads, int d,
+                                 int new_order, void* stream) {
   ADM_REQUIRE(qkv && out, ADM_E_ARG, "adm_attention: null pointer");
   ADM_REQUIRE(n > 0 && t > 0 && heads > 0, ADM_E_ARG, "adm_attention: bad shape n=%d t=%d heads=%d", n, t, heads);
   ADM_REQUIRE(d == 32 || d == 64 || d == 128, ADM_E_SHAPE, "adm_attention: head dim %d unsupported (32, 64, 128)", d);
   ADM_REQUIRE(adm_aligned16(qkv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention: unaligned pointer");
   ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention: n*heads exceeds grid.y");
   AttnK k{};
-  k.qkv = qkv; k.out = out; k.T = t; k.heads = heads;
+  k.qkv = qkv; k.out = out; k.lse = lse; k.T = t; k.heads = heads;
   k.C = heads * d; k.C3 = 3 * k.C;
   if (new_order) { k.q_off = 0; k.k_off = k.C; k.v_off = 2 * k.C; k.head_stride = d; }
   else           { k.q_off = 0; k.k_off = d;   k.v_off = 2 * d;   k.head_stride = 3 * d; }

@@ -1,0 +1,345 @@
+// K10 (attention part): backward-data of QKVAttention for the classifier-guidance gradient.
+//
+// The reference obtains d(log p(y|x))/dx with torch.autograd through EncoderUNetModel
+// (search_imagenet64_classifier_guidance.py:319-326); its AttentionBlocks re-run their forward
+// inside backward (hard-wired checkpoint, guided_diffusion/unet.py:297).  Here the attention
+// backward is a flash-style recomputation from (q, k, v, forward output, log-sum-exp):
+//   delta[q]   = sum_d dA[q,d] * A[q,d]
+//   P          = exp2(S * c - lse),  S = Q K^T,  c = log2(e)/sqrt(D)
+//   dV = P^T dA;   dP = dA V^T;   dS = P o (dP - delta);   dQ = dS K / sqrt(D);   dK = dS^T Q / sqrt(D)
+// Two kernels, no atomics (bitwise reproducible): dQ per 128-query block (loop over key tiles), and
+// dK/dV per 128-key block (loop over query tiles).  All MFMAs are v_mfma_f32_16x16x32_bf16; as in the
+// forward kernel the second product of each chain takes its B operand straight from the first
+// product's accumulators (k-order permuted identically on the LDS-transposed A side).
+#include "adm_common.h"
+
+namespace {
+
+constexpr int TT = 64;        // streamed tile (keys for dQ, queries for dK/dV)
+constexpr int BW = 32;        // rows (queries / keys) owned per wave
+constexpr int BB = 128;       // rows per block
+constexpr int PADE = 8;
+
+struct AttnBwdK {
+  const uint16_t* qkv; const uint16_t* out; const uint16_t* dout; const float* lse; const float* delta;
+  uint16_t* dqkv;
+  int T, heads, C3, C;
+  int q_off, k_off, v_off, head_stride;
+  float scale_log2, inv_sqrt_d;
+};
+
+__global__ void __launch_bounds__(256)
+delta_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout, float* __restrict__ delta,
+             int n, int t, int heads, int d) {
+  const long long items = (long long)n * t * heads;
+  const int c = heads * d;
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+       it += (long long)gridDim.x * blockDim.x) {
+    const int hd = (int)(it % heads);
+    const long long row = it / heads;  // n*t + q
+    const int q = (int)(row % t), img = (int)(row / t);
+    const uint16_t* a = out + row * c + hd * d;
+    const uint16_t* g = dout + row * c + hd * d;
+    float s = 0.f;
+    for (int j = 0; j < d; j += 8) {
+      const uint4 av = *reinterpret_cast<const uint4*>(a + j), gv = *reinterpret_cast<const uint4*>(g + j);
+      const uint32_t au[4] = {av.x, av.y, av.z, av.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s += __uint_as_float(au[e] << 16) * __uint_as_float(gu[e] << 16);
+        s += __uint_as_float(au[e] & 0xffff0000u) * __uint_as_float(gu[e] & 0xffff0000u);
+      }
+    }
+    delta[((long long)img * heads + hd) * t + q] = s;
+  }
+}
+
+// stage a [TT x D] row tile (row-major, optional transposed copy) from a token-major tensor
+template <int D, bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_tile(const uint16_t* base, long long row_stride, int col0, int r0, int rmax,
+                                           uint16_t* rowbuf, uint16_t* trbuf, int tid) {
+  constexpr int KROW = D + PADE, VROW = TT + PADE, UNITS = TT * D / 8;
+#pragma unroll
+  for (int u0 = 0; u0 < UNITS; u0 += 256) {
+    const int u = u0 + tid;
+    if (u < UNITS) {
+      const int r = u / (D / 8), sg = u % (D / 8);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r0 + r < rmax) v = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * row_stride + col0 + sg * 8);
+      if (ROWMAJOR) *reinterpret_cast<uint4*>(&rowbuf[r * KROW + sg * 8]) = v;
+      if (TRANSPOSED) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          trbuf[(sg * 8 + 2 * e) * VROW + r] = (uint16_t)(w[e] & 0xffffu);
+          trbuf[(sg * 8 + 2 * e + 1) * VROW + r] = (uint16_t)(w[e] >> 16);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* trbuf, int vrow, int row, int col) {
+  const uint16_t* vr = trbuf + row * vrow + col;
+  const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+  const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+// ------------------------------------------------------------------------------------ dQ
+template <int D>
+__global__ void __launch_bounds__(256)
+attn_dq_kernel(const AttnBwdK p) {
+  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE, VROW = TT + PADE;
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[TT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[TT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Kt[D * VROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
+  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
+  const int qbase = blockIdx.x * BB + wave * BW;
+  const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
+  const uint16_t* dbase = p.dout + (long long)n * p.T * p.C;
+  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;
+
+  bf16x8 qf[2][KS], gf[2][KS];
+  float lse[2], dl[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qbase + qt * 16 + lc;
+    const bool ok = q < p.T;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        a = *reinterpret_cast<const uint4*>(base + (long long)q * p.C3 + qcol + ks * 32 + lq * 8);
+        g = *reinterpret_cast<const uint4*>(dbase + (long long)q * p.C + hd * D + ks * 32 + lq * 8);
+      }
+      qf[qt][ks] = __builtin_bit_cast(bf16x8, a);
+      gf[qt][ks] = __builtin_bit_cast(bf16x8, g);
+    }
+    const long long si = ((long long)n * p.heads + hd) * p.T + (ok ? q : 0);
+    lse[qt] = ok ? p.lse[si] : 0.f;
+    dl[qt] = ok ? p.delta[si] : 0.f;
+  }
+  f32x4 acc[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (p.T + TT - 1) / TT;
+  for (int t0 = 0; t0 < ntiles; ++t0) {
+    const int k0 = t0 * TT;
+    __syncthreads();
+    stage_tile<D, true, true>(base, p.C3, kcol, k0, p.T, Ks, Kt, tid);
+    stage_tile<D, true, false>(base, p.C3, vcol, k0, p.T, Vs, nullptr, tid);
+    __syncthreads();
+    bf16x8 dsf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 st[2][2], dp[2][2];  // [key tile within the 32-key block][query tile]
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int kt = 2 * kb + kk;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) { st[kk][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            st[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kk][qt], 0, 0, 0);
+            dp[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[qt][ks], dp[kk][qt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kk = e >> 2, r = e & 3;
+          const int key = k0 + (2 * kb + kk) * 16 + lq * 4 + r;
+          float pr = exp2f(st[kk][qt][r] * p.scale_log2 - lse[qt]);
+          if (key >= p.T) pr = 0.f;
+          f[e] = (__bf16)(pr * (dp[kk][qt][r] - dl[qt]));
+        }
+        dsf[qt][kb] = f;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8 kt_f = tr_frag(Kt, VROW, dt * 16 + lc, kb * 32 + lq * 4);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[qt][kb], acc[dt][qt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qbase + qt * 16 + lc;
+    if (q >= p.T) continue;
+    uint16_t* orow = p.dqkv + ((long long)n * p.T + q) * p.C3 + qcol;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x4 o = acc[dt][qt] * p.inv_sqrt_d;
+      uint2 pk;
+      pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+      *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dK, dV
+template <int D>
+__global__ void __launch_bounds__(256)
+attn_dkv_kernel(const AttnBwdK p) {
+  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE, VROW = TT + PADE;
+  __shared__ __attribute__((aligned(16))) uint16_t Qs[TT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Gs[TT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Qt[D * VROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Gt[D * VROW];
+  __shared__ float lse_s[TT], dl_s[TT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
+  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
+  const int kbase = blockIdx.x * BB + wave * BW;
+  const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
+  const uint16_t* dbase = p.dout + (long long)n * p.T * p.C;
+  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;
+
+  // K^T / V^T B-operand fragments of this wave's 32 keys: lane (key lc, quarter lq) holds row[key][ks*32 + 8*lq ..]
+  bf16x8 kf[2][KS], vf[2][KS];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = kbase + kt * 16 + lc;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+      if (key < p.T) {
+        a = *reinterpret_cast<const uint4*>(base + (long long)key * p.C3 + kcol + ks * 32 + lq * 8);
+        b = *reinterpret_cast<const uint4*>(base + (long long)key * p.C3 + vcol + ks * 32 + lq * 8);
+      }
+      kf[kt][ks] = __builtin_bit_cast(bf16x8, a);
+      vf[kt][ks] = __builtin_bit_cast(bf16x8, b);
+    }
+  }
+  f32x4 dv[DT][2], dk[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int ntiles = (p.T + TT - 1) / TT;
+  for (int t0 = 0; t0 < ntiles; ++t0) {
+    const int q0 = t0 * TT;
+    __syncthreads();
+    stage_tile<D, true, true>(base, p.C3, qcol, q0, p.T, Qs, Qt, tid);
+    stage_tile<D, true, true>(dbase, p.C, hd * D, q0, p.T, Gs, Gt, tid);
+    if (tid < TT) {
+      const int q = q0 + tid;
+      const long long si = ((long long)n * p.heads + hd) * p.T + (q < p.T ? q : 0);
+      lse_s[tid] = q < p.T ? p.lse[si] : 0.f;
+      dl_s[tid] = q < p.T ? p.delta[si] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {     // 32-query block of the tile
+      bf16x8 pf[2], dsf[2];             // per key tile
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 st[2], dp[2];              // the block's two 16-query tiles
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int qt = 2 * qb + qq;
+          st[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+            const bf16x8 ga = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+            st[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], st[qq], 0, 0, 0);
+            dp[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[kt][ks], dp[qq], 0, 0, 0);
+          }
+        }
+        bf16x8 f, g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int qq = e >> 2, r = e & 3;
+          const int ql = (2 * qb + qq) * 16 + lq * 4 + r;  // query row within the tile
+          float pr = exp2f(st[qq][r] * p.scale_log2 - lse_s[ql]);
+          if (q0 + ql >= p.T) pr = 0.f;
+          f[e] = (__bf16)pr;
+          g[e] = (__bf16)(pr * (dp[qq][r] - dl_s[ql]));
+        }
+        pf[kt] = f;
+        dsf[kt] = g;
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8 gt_f = tr_frag(Gt, VROW, dt * 16 + lc, qb * 32 + lq * 4);
+        const bf16x8 qt_f = tr_frag(Qt, VROW, dt * 16 + lc, qb * 32 + lq * 4);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt_f, pf[kt], dv[dt][kt], 0, 0, 0);
+          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[kt], dk[dt][kt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = kbase + kt * 16 + lc;
+    if (key >= p.T) continue;
+    uint16_t* orow = p.dqkv + ((long long)n * p.T + key) * p.C3;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const f32x4 a = dk[dt][kt] * p.inv_sqrt_d;
+      const f32x4 b = dv[dt][kt];
+      uint2 pk;
+      pk.x = (uint32_t)adm_f32_to_bf16(a[0]) | ((uint32_t)adm_f32_to_bf16(a[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_bf16(a[2]) | ((uint32_t)adm_f32_to_bf16(a[3]) << 16);
+      *reinterpret_cast<uint2*>(orow + kcol + dt * 16 + lq * 4) = pk;
+      pk.x = (uint32_t)adm_f32_to_bf16(b[0]) | ((uint32_t)adm_f32_to_bf16(b[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_bf16(b[2]) | ((uint32_t)adm_f32_to_bf16(b[3]) << 16);
+      *reinterpret_cast<uint2*>(orow + vcol + dt * 16 + lq * 4) = pk;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_attention_bwd(const adm_bf16* qkv, const adm_bf16* out, const adm_bf16* dout, const float* lse,
+                                 float* delta_ws, adm_bf16* dqkv, int n, int t, int heads, int d, int new_order,
+                                 void* stream) {
+  ADM_REQUIRE(qkv && out && dout && lse && delta_ws && dqkv, ADM_E_ARG, "adm_attention_bwd: null pointer");
+  ADM_REQUIRE(n > 0 && t > 0 && heads > 0, ADM_E_ARG, "adm_attention_bwd: bad shape");
+  ADM_REQUIRE(d == 32 || d == 64, ADM_E_SHAPE, "adm_attention_bwd: head dim %d unsupported (32, 64)", d);
+  ADM_REQUIRE(adm_aligned16(qkv) && adm_aligned16(out) && adm_aligned16(dout) && adm_aligned16(dqkv), ADM_E_ALIGN,
+              "adm_attention_bwd: unaligned pointer");
+  ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention_bwd: n*heads exceeds grid.y");
+  AttnBwdK k{};
+  k.qkv = qkv; k.out = out; k.dout = dout; k.lse = lse; k.delta = delta_ws; k.dqkv = dqkv;
+  k.T = t; k.heads = heads; k.C = heads * d; k.C3 = 3 * k.C;
+  if (new_order) { k.q_off = 0; k.k_off = k.C; k.v_off = 2 * k.C; k.head_stride = d; }
+  else           { k.q_off = 0; k.k_off = d;   k.v_off = 2 * d;   k.head_stride = 3 * d; }
+  k.inv_sqrt_d = 1.0f / sqrtf((float)d);
+  k.scale_log2 = 1.4426950408889634f * k.inv_sqrt_d;
+  hipStream_t s = (hipStream_t)stream;
+  const long long items = (long long)n * t * heads;
+  int blocks = (int)((items + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(delta_kernel, dim3(blocks), dim3(256), 0, s, out, dout, delta_ws, n, t, heads, d);
+  dim3 grid((t + BB - 1) / BB, n * heads);
+  if (d == 32) {
+    hipLaunchKernelGGL((attn_dq_kernel<32>), grid, dim3(256), 0, s, k);
+    hipLaunchKernelGGL((attn_dkv_kernel<32>), grid, dim3(256), 0, s, k);
+  } else {
+    hipLaunchKernelGGL((attn_dq_kernel<64>), grid, dim3(256), 0, s, k);
+    hipLaunchKernelGGL((attn_dkv_kernel<64>), grid, dim3(256), 0, s, k);
+  }
+  return adm_check_launch("adm_attention_bwd");
+}

@@ -107,7 +107,7 @@ gn_partial_kernel(const uint16_t* __restrict__ in0, int c0, const uint16_t* __re
 __global__ void __launch_bounds__(256)
 gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
                    const float* __restrict__ film, int film_stride, float* __restrict__ aff_a,
-                   float* __restrict__ aff_b, int c, int hw, int slabs, float eps) {
+                   float* __restrict__ aff_b, float* __restrict__ stats, int c, int hw, int slabs, float eps) {
   __shared__ float gmean[32], grstd[32];
   const int img = blockIdx.x;
   const int cpg = c / 32;
@@ -132,6 +132,10 @@ gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ 
     if (var < 0.0) var = 0.0;
     gmean[grp] = (float)mean;
     grstd[grp] = (float)(1.0 / sqrt(var + (double)eps));
+    if (stats) {  // kept for the backward-data pass (classifier guidance)
+      stats[((long long)img * 32 + grp) * 2 + 0] = gmean[grp];
+      stats[((long long)img * 32 + grp) * 2 + 1] = grstd[grp];
+    }
   }
   __syncthreads();
   for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
@@ -234,13 +238,13 @@ extern "C" int adm_gn_partial(const adm_bf16* in0, int c0, const adm_bf16* in1, 
 }
 
 extern "C" int adm_gn_finalize(const float* partial, const float* gamma, const float* beta, const float* film,
-                               int film_stride, float* aff_a, float* aff_b, int n, int c, int hw, int slabs,
-                               float eps, void* stream) {
+                               int film_stride, float* aff_a, float* aff_b, float* stats, int n, int c, int hw,
+                               int slabs, float eps, void* stream) {
   ADM_REQUIRE(partial && gamma && beta && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize: null pointer");
   ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0, ADM_E_SHAPE, "adm_gn_finalize: bad shape");
   ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize: film_stride < 2*c");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, film,
-                     film_stride, aff_a, aff_b, c, hw, slabs, eps);
+                     film_stride, aff_a, aff_b, stats, c, hw, slabs, eps);
   return adm_check_launch("adm_gn_finalize");
 }
 

@@ -115,10 +115,11 @@ def gn_slabs(hw: int) -> int:
     return max(1, min(64, hw // 64))
 
 
-def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None):
+def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, want_stats=False):
     """GroupNorm32 statistics of the virtual concat (x0 | x1) -> per-(image, channel) affine (a, b).
 
     film: fp32 view whose row n, columns [0:C) = scale and [C:2C) = shift (row stride film_stride).
+    want_stats: also return fp32 [N, 32, 2] (mean, rstd) for the backward-data pass.
     """
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
@@ -136,9 +137,12 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None):
         if film.dtype != torch.float32 or not film.is_cuda:
             raise AdmError("film must be a float32 device tensor")
         film_ptr = film.data_ptr()
+    stats = torch.empty((n, 32, 2), dtype=torch.float32, device=x0.device) if want_stats else None
     check(lib.adm_gn_finalize(_ptr(partial), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
-                              film_ptr, film_stride, _ptr(a), _ptr(b), n, c, hw, slabs, GN_EPS, _stream()),
-          "adm_gn_finalize")
+                              film_ptr, film_stride, _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, GN_EPS,
+                              _stream()), "adm_gn_finalize")
+    if want_stats:
+        return a, b, stats
     return a, b
 
 
@@ -209,12 +213,115 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
 
 
 # ------------------------------------------------------------------ attention
-def attention(qkv, heads: int, new_order: bool):
-    """qkv bf16 [N, T, 3*H*D] -> bf16 [N, T, H*D]."""
+def attention(qkv, heads: int, new_order: bool, want_lse: bool = False):
+    """qkv bf16 [N, T, 3*H*D] -> bf16 [N, T, H*D] (and the fp32 [N, H, T] log-sum-exp if want_lse)."""
     n, t, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
     out = torch.empty((n, t, c), dtype=BF16, device=qkv.device)
-    check(_lib.load().adm_attention(_ptr(qkv, BF16, "qkv"), _ptr(out), n, t, heads, d, int(new_order), _stream()),
-          "adm_attention")
+    lse = torch.empty((n, heads, t), dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(_lib.load().adm_attention_lse(_ptr(qkv, BF16, "qkv"), _ptr(out), _ptr(lse), n, t, heads, d,
+                                        int(new_order), _stream()), "adm_attention")
+    return (out, lse) if want_lse else out
+
+
+# ------------------------------------------------------------------ backward-data (classifier guidance)
+def attention_bwd(qkv, out, dout, lse, heads: int, new_order: bool):
+    n, t, c3 = qkv.shape
+    d = c3 // 3 // heads
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((n, heads, t), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().adm_attention_bwd(_ptr(qkv, BF16, "qkv"), _ptr(out, BF16, "out"), _ptr(dout, BF16, "dout"),
+                                        _ptr(lse, torch.float32, "lse"), _ptr(delta), _ptr(dqkv), n, t, heads, d,
+                                        int(new_order), _stream()), "adm_attention_bwd")
+    return dqkv
+
+
+def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=False):
+    """Backward of y = act(a*x+b) (GroupNorm(+FiLM)(+SiLU)): returns dx bf16 NHWC (+ add)."""
+    n, h, w, c = x.shape
+    hw = h * w
+    lib = _lib.load()
+    slabs = gn_slabs(hw)
+    partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x.device)
+    k1 = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    k0 = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    a, b = aff
+    check(lib.adm_gn_bwd_partial(_ptr(x, BF16, "x"), _ptr(dy, BF16, "dy"), _ptr(a, torch.float32), _ptr(b, torch.float32),
+                                 _ptr(partial), n, h, w, c, slabs, int(silu), int(dy_half), _stream()),
+          "adm_gn_bwd_partial")
+    check(lib.adm_gn_bwd_finalize(_ptr(partial), _ptr(a), _ptr(stats, torch.float32, "stats"), _ptr(k1), _ptr(k0),
+                                  n, c, hw, slabs, _stream()), "adm_gn_bwd_finalize")
+    out = torch.empty_like(x)
+    check(lib.adm_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(a), _ptr(b), _ptr(k1), _ptr(k0), _ptr(add, BF16, "add"),
+                               _ptr(out), n, h, w, c, int(silu), int(dy_half), int(add_half), _stream()),
+          "adm_gn_bwd_apply")
+    return out
+
+
+def grad_add(a, b, b_half=False):
+    n, h, w, c = a.shape
+    out = torch.empty_like(a)
+    check(_lib.load().adm_grad_add(_ptr(a, BF16, "a"), _ptr(b, BF16, "b"), _ptr(out), n, h, w, c, int(b_half),
+                                   _stream()), "adm_grad_add")
+    return out
+
+
+def logsoftmax_grad(logits, y, scale: float):
+    n, k = logits.shape
+    dl = torch.empty_like(logits)
+    check(_lib.load().adm_logsoftmax_grad(_ptr(logits, torch.float32, "logits"), _ptr(y, torch.int64, "y"), _ptr(dl),
+                                          None, n, k, float(scale), _stream()), "adm_logsoftmax_grad")
+    return dl
+
+
+def pool_prep(h, aff, pos, tpad: int):
+    n, hh, ww, c = h.shape
+    tok = torch.empty((n, tpad, c), dtype=BF16, device=h.device)
+    check(_lib.load().adm_pool_prep(_ptr(h, BF16, "h"), _ptr(aff[0], torch.float32), _ptr(aff[1], torch.float32),
+                                    _ptr(pos, torch.float32, "pos"), _ptr(tok), n, hh * ww, c, tpad, _stream()),
+          "adm_pool_prep")
+    return tok
+
+
+def pool_attn_fwd(qkv, t: int, heads: int):
+    n, tpad, c3 = qkv.shape
+    c = c3 // 3
+    a0 = torch.empty((n, c), dtype=torch.float32, device=qkv.device)
+    wts = torch.empty((n, heads, tpad), dtype=torch.float32, device=qkv.device)
+    check(_lib.load().adm_pool_attn_fwd(_ptr(qkv, BF16, "qkv"), _ptr(a0), _ptr(wts), n, t, tpad, heads, c // heads,
+                                        _stream()), "adm_pool_attn_fwd")
+    return a0, wts
+
+
+def pool_attn_bwd(qkv, wts, da0, t: int, heads: int):
+    n, tpad, c3 = qkv.shape
+    c = c3 // 3
+    dqkv = torch.empty_like(qkv)
+    check(_lib.load().adm_pool_attn_bwd(_ptr(qkv, BF16, "qkv"), _ptr(wts, torch.float32), _ptr(da0, torch.float32),
+                                        _ptr(dqkv), n, t, tpad, heads, c // heads, _stream()), "adm_pool_attn_bwd")
+    return dqkv
+
+
+def pool_prep_bwd(dtok, hh: int, ww: int):
+    n, tpad, c = dtok.shape
+    dact = torch.empty((n, hh, ww, c), dtype=BF16, device=dtok.device)
+    check(_lib.load().adm_pool_prep_bwd(_ptr(dtok, BF16, "dtok"), _ptr(dact), n, hh * ww, c, tpad, _stream()),
+          "adm_pool_prep_bwd")
+    return dact
+
+
+def pack_conv_weight_bwd(w):
+    """Backward-data image of a conv weight [cout, cin, ...]: conv with cin' = cout, cout' = cin, flipped taps."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = 1
+    for s in w.shape[2:]:
+        taps *= s
+    lib = _lib.load()
+    elems = lib.adm_packed_weight_elems(cin, cout, taps)
+    if elems < 0:
+        raise AdmError(f"pack_conv_weight_bwd: unsupported weight shape {tuple(w.shape)} (cout % 32 == 0, taps 1|9)")
+    w32 = w.detach().to(torch.float32).contiguous()
+    out = torch.empty((elems,), dtype=BF16, device=w.device)
+    check(lib.adm_pack_conv_weight_bwd(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight_bwd")
     return out

@@ -148,10 +148,10 @@ class _Prep:
     pass
 
 
-class UNetModel(HipModule):
+class AdmNet(HipModule):
+    """Blocks shared by the UNet and the classifier half-UNet."""
+
     def __init__(self, plan: UNetPlan, use_fp16: bool = False):
-        if plan.encoder_only:
-            raise ValueError("use EncoderUNetModel for classifier plans")
         super().__init__(plan, use_fp16)
         self.image_size = plan.image_size
         self.in_channels = plan.in_channels
@@ -164,6 +164,8 @@ class UNetModel(HipModule):
             if isinstance(b, ResBlockSpec) and not b.scale_shift:
                 raise NotImplementedError("use_scale_shift_norm=False is not built on the HIP path "
                                           "(every reference launch script sets it True)")
+
+    with_backward = False  # classifier: also pack the backward-data weight images
 
     # ------------------------------------------------------------------ weight preparation
     def _prepare(self):
@@ -209,15 +211,34 @@ class UNetModel(HipModule):
         pr.film_w = torch.cat(ws, dim=0).contiguous()
         pr.film_b = torch.cat(bs, dim=0).contiguous()
         pr.film_total = off
-        h = self.plan.head
-        if isinstance(h, HeadSpec):
-            pr.head = dict(g=f32(f"{h.prefix}.0.weight"), b=f32(f"{h.prefix}.0.bias"),
-                           w=ops.pack_conv_weight(P[f"{h.prefix}.2.weight"]), cb=f32(f"{h.prefix}.2.bias"))
+        if self.with_backward:
+            zmax = 0
+            for b in self.plan.all_blocks():
+                p = b.prefix
+                d = pr.blocks[p]
+                if isinstance(b, StemSpec):
+                    d["w_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.weight"])
+                    zmax = max(zmax, b.cin, b.cout)
+                elif isinstance(b, ResBlockSpec):
+                    d["w1_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.in_layers.2.weight"])
+                    d["w2_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.out_layers.3.weight"])
+                    if b.has_skip_conv:
+                        d["ws_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.skip_connection.weight"])
+                    zmax = max(zmax, b.cin, b.cout)
+                elif isinstance(b, AttnSpec):
+                    d["wqkv_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.qkv.weight"])
+                    d["wproj_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.proj_out.weight"])
+                    zmax = max(zmax, 3 * b.channels)
+            pr.zero_bias = torch.zeros(zmax, dtype=torch.float32, device=dev)
+        self._prepare_head(pr, P, f32)
         self._packed = pr
         return pr
 
+    def _prepare_head(self, pr, P, f32):
+        pass
+
     # ------------------------------------------------------------------ blocks
-    def _resblock(self, pr, s: ResBlockSpec, x0, x1, film, skipped):
+    def _resblock(self, pr, s: ResBlockSpec, x0, x1, film, skipped, tape=None):
         d = pr.blocks[s.prefix]
         mode = "up" if s.up else ("down" if s.down else None)
         if skipped:  # dynamic_unet.py:245-250: body bypassed, x_upd + skip_connection kept
@@ -225,7 +246,12 @@ class UNetModel(HipModule):
             if s.has_skip_conv:
                 return ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=x1)
             return xs
-        aff1 = ops.gn_affine(x0, d["g1"], d["b1"], x1)
+        st1 = st2 = None
+        if tape is not None:
+            a1, b1, st1 = ops.gn_affine(x0, d["g1"], d["b1"], x1, want_stats=True)
+            aff1 = (a1, b1)
+        else:
+            aff1 = ops.gn_affine(x0, d["g1"], d["b1"], x1)
         if mode:
             assert x1 is None
             h_in = ops.resample(x0, mode, aff1)
@@ -236,33 +262,49 @@ class UNetModel(HipModule):
             h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True)
             xs, xs1 = x0, x1
         off = pr.film_off[s.prefix]
-        aff2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total)
+        if tape is not None:
+            a2, b2, st2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total,
+                                        want_stats=True)
+            aff2 = (a2, b2)
+            tape.append(("res", s, dict(x=x0, aff1=aff1, st1=st1, h1=h, aff2=aff2, st2=st2)))
+        else:
+            aff2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total)
         if s.has_skip_conv:
             res = ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=xs1)
         else:
             res = xs
         return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res)
 
-    def _attention(self, pr, s: AttnSpec, x, skipped):
+    def _attention(self, pr, s: AttnSpec, x, skipped, tape=None):
         if skipped:  # dynamic_unet.py:316-318
             return x
         d = pr.blocks[s.prefix]
         n, hh, ww, c = x.shape
-        aff = ops.gn_affine(x, d["g"], d["b"])
+        if tape is not None:
+            a_, b_, st = ops.gn_affine(x, d["g"], d["b"], want_stats=True)
+            aff = (a_, b_)
+        else:
+            aff = ops.gn_affine(x, d["g"], d["b"])
         qkv = ops.conv(x, d["wqkv"], d["bqkv"], 3 * c, 1, aff=aff, silu=False)
-        a = ops.attention(qkv.view(n, hh * ww, 3 * c), s.num_heads, s.new_order)
+        if tape is not None:
+            a, lse = ops.attention(qkv.view(n, hh * ww, 3 * c), s.num_heads, s.new_order, want_lse=True)
+            tape.append(("attn", s, dict(x=x, aff=aff, st=st, qkv=qkv, a=a, lse=lse)))
+        else:
+            a = ops.attention(qkv.view(n, hh * ww, 3 * c), s.num_heads, s.new_order)
         return ops.conv(a.view(n, hh, ww, c), d["wproj"], d["bproj"], c, 1, res=x)
 
-    def _run_seq(self, pr, seq, h, skip, film, skip_ids, x_nchw=None):
+    def _run_seq(self, pr, seq, h, skip, film, skip_ids, x_nchw=None, tape=None):
         first = True
         for blk in seq:
             if isinstance(blk, StemSpec):
                 d = pr.blocks[blk.prefix]
                 h = ops.stem_conv3x3(x_nchw, d["w"], d["b"])
+                if tape is not None:
+                    tape.append(("stem", blk, {}))
             elif isinstance(blk, ResBlockSpec):
-                h = self._resblock(pr, blk, h, skip if first else None, film, blk.layer_id in skip_ids)
+                h = self._resblock(pr, blk, h, skip if first else None, film, blk.layer_id in skip_ids, tape)
             else:
-                h = self._attention(pr, blk, h, blk.layer_id in skip_ids)
+                h = self._attention(pr, blk, h, blk.layer_id in skip_ids, tape)
             first = False
         return h
 
@@ -280,6 +322,18 @@ class UNetModel(HipModule):
         else:
             e = ops.linear_f32(e, pr.te2_w, pr.te2_b, silu_in=True)
         return ops.linear_f32(e, pr.film_w, pr.film_b, silu_in=True)  # every block's (scale | shift)
+
+
+class UNetModel(AdmNet):
+    def __init__(self, plan: UNetPlan, use_fp16: bool = False):
+        if plan.encoder_only:
+            raise ValueError("use EncoderUNetModel for classifier plans")
+        super().__init__(plan, use_fp16)
+
+    def _prepare_head(self, pr, P, f32):
+        h = self.plan.head
+        pr.head = dict(g=f32(f"{h.prefix}.0.weight"), b=f32(f"{h.prefix}.0.bias"),
+                       w=ops.pack_conv_weight(P[f"{h.prefix}.2.weight"]), cb=f32(f"{h.prefix}.2.bias"))
 
     def forward(self, x, timesteps, y=None, skip_layer: Sequence[int] = ()):
         """x fp32 [N,C,H,W], timesteps [N] (original-process timesteps), y int64 [N] or None."""

@@ -107,6 +107,7 @@ int adm_gn_partial(const adm_bf16* in0, int c0, const adm_bf16* in1, int c1, flo
                    int n, int hw, int slabs, void* stream);
 int adm_gn_finalize(const float* partial, const float* gamma, const float* beta,
                     const float* film, int film_stride, float* aff_a, float* aff_b,
+                    float* stats /* nullable: [N][32][2] = (mean, rstd), kept for adm_gn_bwd_* */,
                     int n, int c, int hw, int slabs, float eps, void* stream);
 
 /* h_upd / x_upd of an up/down ResBlock (unet.py:190-195, 237-242):
@@ -151,6 +152,64 @@ int adm_pack_conv_weight(const float* w, adm_bf16* out, int cout, int cin, int t
  * D in {32, 64, 128}.                                                                     */
 int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, int d,
                   int new_order, void* stream);
+
+/* Same, also writing the log2-domain log-sum-exp of the scaled logits, fp32 [N][H][T] (nullable):
+ * P = exp2(s * log2(e)/sqrt(D) - lse).  Needed by adm_attention_bwd.                          */
+int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int t, int heads, int d,
+                      int new_order, void* stream);
+
+/* ---------------------------------------------------------------- classifier guidance, backward-data (K10, A9)
+ * The reference gets grad_x log p(y|x,t) from torch.autograd over EncoderUNetModel
+ * (search_imagenet64_classifier_guidance.py:319-326, unet.py:685-896).  Here the backward network
+ * is explicit; only data gradients exist (no weight gradients).
+ *
+ * Attention backward (flash-style recomputation; unet.py:297 re-runs the forward too):
+ * qkv / dqkv bf16 [N][T][3*H*D], out / dout bf16 [N][T][H*D], lse from adm_attention_lse,
+ * delta_ws fp32 [N][H][T] workspace.  D in {32, 64}.                                          */
+int adm_attention_bwd(const adm_bf16* qkv, const adm_bf16* out, const adm_bf16* dout, const float* lse,
+                      float* delta_ws, adm_bf16* dqkv, int n, int t, int heads, int d, int new_order,
+                      void* stream);
+
+/* GroupNorm(+FiLM)(+SiLU) backward for y = act(a*x + b) with (a, b, stats) from adm_gn_finalize:
+ *   dx = a*dz + k1*x + k0 (+ add),  dz = dy * SiLU'(a*x+b)  (dz = dy when silu == 0).
+ * partial: fp32 [N][slabs][C][2]; k1/k0: fp32 [N][C].  dy_half / add_half: that tensor lives at
+ * (h/2, w/2) and is read as 0.25 * t[y/2, x/2] (AvgPool2d backward of down ResBlocks).          */
+int adm_gn_bwd_partial(const adm_bf16* x, const adm_bf16* dy, const float* aff_a, const float* aff_b,
+                       float* partial, int n, int h, int w, int c, int slabs, int silu, int dy_half,
+                       void* stream);
+int adm_gn_bwd_finalize(const float* partial, const float* aff_a, const float* stats, float* k1, float* k0,
+                        int n, int c, int hw, int slabs, void* stream);
+int adm_gn_bwd_apply(const adm_bf16* x, const adm_bf16* dy, const float* aff_a, const float* aff_b,
+                     const float* k1, const float* k0, const adm_bf16* add, adm_bf16* out,
+                     int n, int h, int w, int c, int silu, int dy_half, int add_half, void* stream);
+/* out = a + (b_half ? 0.25 * b[y/2, x/2] : b): gradient accumulation at a fan-out.             */
+int adm_grad_add(const adm_bf16* a, const adm_bf16* b, adm_bf16* out, int n, int h, int w, int c,
+                 int b_half, void* stream);
+
+/* dlogits = scale * (onehot(y) - softmax(logits)) = scale * d/dlogits sum_n log_softmax[n, y_n];
+ * logp_sel (nullable) receives log_softmax[n, y_n].  fp32 [N][K].                              */
+int adm_logsoftmax_grad(const float* logits, const int64_t* y, float* dlogits, float* logp_sel,
+                        int n, int k, float scale, void* stream);
+
+/* AttentionPool2d (unet.py:22-51) around its single used query (token 0):
+ *   adm_pool_prep     tok[n,0,:] = mean_p act + pos[:,0]; tok[n,1+p,:] = act[n,p,:] + pos[:,1+p],
+ *                     act = SiLU(a*h + b); tok bf16 [N][tpad][C] (rows >= HW+1 zero); pos fp32 [C][HW+1]
+ *   (qkv_proj = adm_conv 1x1 on tok viewed as 8x8 maps)
+ *   adm_pool_attn_fwd a0[n,:] = attention output of token 0 (fp32 [N][C]); wts fp32 [N][H][tpad]
+ *   (c_proj = adm_linear_f32)
+ *   adm_pool_attn_bwd dqkv bf16 [N][tpad][3C] from da0 fp32 [N][C]
+ *   adm_pool_prep_bwd d_act[n,p,:] = dtok[n,1+p,:] + dtok[n,0,:]/HW                               */
+int adm_pool_prep(const adm_bf16* h, const float* aff_a, const float* aff_b, const float* pos, adm_bf16* tok,
+                  int n, int hw, int c, int tpad, void* stream);
+int adm_pool_attn_fwd(const adm_bf16* qkv, float* a0, float* wts, int n, int t, int tpad, int heads, int d,
+                      void* stream);
+int adm_pool_attn_bwd(const adm_bf16* qkv, const float* wts, const float* da0, adm_bf16* dqkv, int n, int t,
+                      int tpad, int heads, int d, void* stream);
+int adm_pool_prep_bwd(const adm_bf16* dtok, adm_bf16* dact, int n, int hw, int c, int tpad, void* stream);
+
+/* Backward-data weight image for adm_conv: the conv with cin' = cout, cout' = cin and
+ * w'[ci][co][t] = w[co][ci][taps-1-t].  out holds adm_packed_weight_elems(cin, cout, taps).     */
+int adm_pack_conv_weight_bwd(const float* w, adm_bf16* out, int cout, int cin, int taps, void* stream);
 
 #ifdef __cplusplus
 }
