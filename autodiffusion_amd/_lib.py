@@ -70,6 +70,7 @@ SIGNATURES = {
     "adm_pool_attn_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_pool_prep_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "adm_pack_conv_weight_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
 }
 
 _lib = None

@@ -1,0 +1,122 @@
+"""FID statistics for candidate scoring: GPU accumulation, RCCL pooling, host Frechet distance.
+
+Mirrors reference evaluations/evaluator_v1.py: ``FIDStatistics`` (:109-157),
+``Evaluator.compute_statistics`` (:218-221) and ``cal_fid`` (:730-753).
+
+* The 2048-d activations of a batch are folded into float64 running sums on the GPU
+  (``adm_fid_accumulate``): no [N, 2048] array is gathered or copied to the host.
+* With several ranks, each rank accumulates the activations of ITS images; ``pooled()`` runs ONE
+  ``all_gather`` of (n, s1, s2) per candidate -- RCCL over xGMI on GPUs, gloo in the CPU tests --
+  and sums the shards in rank order (bitwise deterministic).  This replaces the reference's
+  per-batch uint8 image all_gather (search_imagenet64_classifier_guidance.py:356-361).
+* ``frechet_distance`` keeps the reference's float64 scipy ``sqrtm`` formula on the host.
+
+The Inception-v3 pool3 extractor itself (a frozen TensorFlow graph fetched from a URL,
+evaluator_v1.py:652-679) is third-party and not available offline; any callable
+``features(uint8 NHWC device batch) -> fp32 [B, D] device tensor`` (or the reference's own
+``Evaluator_v1``) plugs in.  "Parity unpinned" for the features themselves.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Optional
+
+import numpy as np
+import torch
+from scipy import linalg
+
+from . import _lib
+from ._lib import check
+
+
+class FIDStatistics:
+    def __init__(self, mu: np.ndarray, sigma: np.ndarray):
+        self.mu = mu
+        self.sigma = sigma
+
+    def frechet_distance(self, other, eps=1e-6):
+        mu1, sigma1 = np.atleast_1d(self.mu), np.atleast_2d(self.sigma)
+        mu2, sigma2 = np.atleast_1d(other.mu), np.atleast_2d(other.sigma)
+        assert mu1.shape == mu2.shape, \
+            "Training and test mean vectors have different lengths: " + str(mu1.shape) + ', ' + str(mu2.shape)
+        assert sigma1.shape == sigma2.shape, \
+            "Training and test mean vectors have different lengths: " + str(sigma1.shape) + ', ' + str(sigma2.shape)
+        diff = mu1 - mu2
+        covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+        if not np.isfinite(covmean).all():
+            warnings.warn("fid calculation produces singular product; adding %s to diagonal of cov estimates" % eps)
+            offset = np.eye(sigma1.shape[0]) * eps
+            covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+        if np.iscomplexobj(covmean):
+            if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+                raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
+            covmean = covmean.real
+        return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+
+
+def compute_statistics(activations: np.ndarray) -> FIDStatistics:
+    """Host form (np.mean / np.cov), used when the activations already live on the host."""
+    return FIDStatistics(np.mean(activations, axis=0), np.cov(activations, rowvar=False))
+
+
+class ActivationAccumulator:
+    """Running (n, sum a, sum a a^T) of fp32 activations; float64 on the device that produces them."""
+
+    def __init__(self, dim: int, device):
+        self.dim = dim
+        self.device = torch.device(device)
+        self.n = 0
+        self.s1 = torch.zeros(dim, dtype=torch.float64, device=self.device)
+        self.s2 = torch.zeros(dim, dim, dtype=torch.float64, device=self.device)
+
+    def add(self, acts: torch.Tensor, limit: Optional[int] = None):
+        """acts fp32 [B, dim]; `limit` keeps only the first rows (the reference's arr[:num_samples])."""
+        if limit is not None:
+            acts = acts[:limit]
+        if acts.shape[0] == 0:
+            return
+        acts = acts.to(torch.float32).contiguous()
+        if self.device.type != "cuda" or not acts.is_cuda:
+            raise _lib.AdmError("ActivationAccumulator.add: activations must be device tensors "
+                                "(the statistics kernel has no CPU fallback)")
+        lib = _lib.load()
+        check(lib.adm_fid_accumulate(acts.data_ptr(), self.s1.data_ptr(), self.s2.data_ptr(), acts.shape[0],
+                                     self.dim, torch.cuda.current_stream().cuda_stream), "adm_fid_accumulate")
+        self.n += int(acts.shape[0])
+
+    def pooled(self, group=None):
+        """(n, s1, s2) summed over ranks with one all_gather per tensor, in rank order."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self.n, self.s1, self.s2
+        world = dist.get_world_size(group)
+        nt = torch.tensor([self.n], dtype=torch.int64, device=self.device)
+        ns = [torch.zeros_like(nt) for _ in range(world)]
+        s1s = [torch.zeros_like(self.s1) for _ in range(world)]
+        s2s = [torch.zeros_like(self.s2) for _ in range(world)]
+        dist.all_gather(ns, nt, group=group)
+        dist.all_gather(s1s, self.s1, group=group)
+        dist.all_gather(s2s, self.s2, group=group)
+        n = int(sum(int(v.item()) for v in ns))
+        s1, s2 = s1s[0].clone(), s2s[0].clone()
+        for r in range(1, world):
+            s1 += s1s[r]
+            s2 += s2s[r]
+        return n, s1, s2
+
+    def statistics(self, group=None) -> FIDStatistics:
+        n, s1, s2 = self.pooled(group)
+        if n < 2:
+            raise ValueError("need at least 2 activations for a covariance")
+        s1 = s1.cpu().numpy()
+        s2 = s2.cpu().numpy()
+        mu = s1 / n
+        sigma = (s2 - n * np.outer(mu, mu)) / (n - 1)
+        return FIDStatistics(mu, sigma)
+
+
+def cal_fid(batches, batch_size, evaluator, ref_stats, ref_stats_spatial=None):
+    """Reference signature (evaluator_v1.py:730): uint8 NHWC numpy array + an evaluator object."""
+    acts = evaluator.compute_activations(batches, batch_size)
+    pool = acts[0] if isinstance(acts, (tuple, list)) else acts
+    return compute_statistics(np.asarray(pool)).frechet_distance(ref_stats)

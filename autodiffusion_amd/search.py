@@ -1,0 +1,277 @@
+"""Evolutionary search over timestep subsets -- the reference's driver on the HIP evaluation path.
+
+Drop-in mirror of ``EvolutionSearcher`` (reference search_imagenet64_classifier_guidance.py:155-584;
+unconditional variant search_uncondition_model.py; dict candidates with per-step skip lists are
+accepted by ``get_cand_fid`` as in search_dynamic_unet_imagenet64_classifier_guidance_progressive.py
+:369-445).  The EA operators consume ``random`` / ``np.random`` in exactly the reference's order
+(pinned by tests/golden/ea_trajectory.npz), the log lines keep the reference's text, and
+``get_cand_fid(cand, args) -> float`` keeps its signature and side effects.
+
+What changes underneath:
+  * sampling runs on the HIP engine (evaluate.CandidateEvaluator); images never leave the GPU;
+  * FID statistics are accumulated on the GPU and pooled over ranks with one all-gather per
+    candidate (fid.ActivationAccumulator) instead of all-gathering every uint8 batch;
+  * every batch is seeded by (seed, candidate, batch index, rank), so a candidate's FID does not depend
+    on how the work was sharded;
+  * the Inception feature extractor is a plug-in: ``features(uint8 NHWC device batch) -> [B, D]``
+    or the reference's own ``Evaluator_v1`` object (then the reference's host cal_fid path is used).
+"""
+from __future__ import annotations
+
+import random
+import time
+import zlib
+
+import numpy as np
+import torch
+
+from . import dist_util, logger
+from .evaluate import CandidateEvaluator
+from .fid import ActivationAccumulator, FIDStatistics, cal_fid
+from .schedule import space_timesteps
+
+choice = lambda x: x[np.random.randint(len(x))] if isinstance(x, tuple) else choice(tuple(x))  # noqa: E731
+
+
+class EvolutionSearcher(object):
+
+    def __init__(self, args, model, base_diffusion, time_step, classifier=None, search_space=None,
+                 evaluator=None, ref_stats=None, features=None, feature_dim=2048, variant=None):
+        self.args = args
+        self.model = model
+        self.base_diffusion = base_diffusion
+        self.classifier = classifier
+        self.time_step = time_step
+        self.max_epochs = args.max_epochs
+        self.select_num = args.select_num
+        self.population_num = args.population_num
+        self.m_prob = args.m_prob
+        self.crossover_num = args.crossover_num
+        self.mutation_num = args.mutation_num
+        self.keep_top_k = {self.select_num: [], 50: []}
+        self.epoch = 0
+        self.candidates = []
+        self.vis_dict = {}
+        self.max_fid = getattr(args, "max_fid", 48.0)
+        self.thres = getattr(args, "thres", 0.2)
+        self.search_space = search_space
+        self.x0 = getattr(args, "init_x", "")
+        # "guided" = search_imagenet64_classifier_guidance.py, "unconditional" = search_uncondition_model.py
+        # (the latter seeds pop//2 random candidates instead of pop//2 + 1 and stops before the last
+        # epoch's offspring, :509-532, :554-555)
+        self.variant = variant or ("guided" if classifier is not None else "unconditional")
+        self.break_at_last_epoch = self.variant == "unconditional"
+        # FID plumbing: reference-style evaluator object, or a device feature function
+        self.evaluator = evaluator
+        self.features = features
+        self.feature_dim = feature_dim
+        self.ref_stats = ref_stats
+        if ref_stats is None and getattr(args, "ref_path", ""):
+            # the reference pickles a FIDStatistics; this build reads the two arrays from an .npz
+            # (mu, sigma) written from it -- unpickling foreign files is not done here
+            z = np.load(args.ref_path, allow_pickle=False)
+            self.ref_stats = FIDStatistics(z["mu"], z["sigma"])
+        self._ev = None
+        if model is not None:
+            self._ev = CandidateEvaluator(
+                model, base_diffusion, classifier, image_size=args.image_size, use_ddim=args.use_ddim,
+                clip_denoised=args.clip_denoised, class_cond=args.class_cond,
+                classifier_scale=getattr(args, "classifier_scale", 1.0), device=dist_util.dev())
+            self.active_diffusion = self._ev.active_diffusion
+
+    # ------------------------------------------------------------------ evaluate-candidate interface
+    def reset_diffusion(self, use_timesteps):
+        self._ev.set_candidate(list(use_timesteps))
+
+    def get_cand_fid(self, cand=None, args=None):
+        args = args if args is not None else self.args
+        t1 = time.time()
+        self._ev.set_candidate(cand)
+        reset_time = time.time() - t1
+        t1 = time.time()
+        logger.log("sampling...")
+        world, rank = dist_util.get_world_size(), dist_util.get_rank()
+        seed0 = (int(getattr(args, "seed", 0)) * 1000003 + zlib.crc32(str(cand).encode())) & 0x7FFFFFFF
+        acc = ActivationAccumulator(self.feature_dim, self._ev.device) if self.features is not None else None
+        host_images = []
+        produced = 0
+        batch_idx = 0
+        while produced < args.num_samples:
+            u8 = self._ev.sample_batch(args.batch_size, seed=seed0 + 7919 * (batch_idx * world + rank))
+            # the reference keeps arr[:num_samples] of the rank-major concatenation of every round
+            start = produced + rank * args.batch_size
+            keep = max(0, min(args.batch_size, args.num_samples - start))
+            if acc is not None:
+                if keep > 0:
+                    acc.add(self.features(u8[:keep]))
+            else:
+                host_images.append(u8[:keep].cpu().numpy())
+            produced += args.batch_size * world
+            batch_idx += 1
+            logger.log('created ' + str(min(produced, batch_idx * args.batch_size * world)) + ' samples')
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        logger.log("sampling complete")
+        sample_time = time.time() - t1
+        t1 = time.time()
+        if acc is not None:
+            fid = float(acc.statistics().frechet_distance(self.ref_stats))
+        else:
+            if world > 1:
+                raise NotImplementedError("host-evaluator FID with several ranks: pass a device `features` function "
+                                          "so that statistics are pooled on the GPUs")
+            arr = np.concatenate(host_images, axis=0)[: args.num_samples]
+            fid = float(cal_fid(arr, 64, self.evaluator, ref_stats=self.ref_stats))
+        fid_time = time.time() - t1
+        logger.log('reset_time: ' + str(reset_time) + ', sample_time: ' + str(sample_time) + ', fid_time: ' + str(fid_time))
+        return fid
+
+    # ------------------------------------------------------------------ EA bookkeeping (reference order of RNG draws)
+    def update_top_k(self, candidates, *, k, key, reverse=False):
+        assert k in self.keep_top_k
+        logger.log('select ......')
+        t = self.keep_top_k[k]
+        t += candidates
+        t.sort(key=key, reverse=reverse)
+        self.keep_top_k[k] = t[:k]
+
+    def sample_active_subnet(self):
+        if self.search_space is not None:
+            use_timestep = self.search_space  # shuffled in place, as the reference does
+        else:
+            use_timestep = [i for i in range(self.base_diffusion.original_num_steps)]
+        random.shuffle(use_timestep)
+        return use_timestep[:self.time_step]
+
+    def _visit(self, cand):
+        if cand not in self.vis_dict:
+            self.vis_dict[cand] = {}
+        info = self.vis_dict[cand]
+        if 'visited' in info:
+            logger.log('cand: {} has visited!'.format(cand))
+            return False
+        info['fid'] = self.get_cand_fid(args=self.args, cand=eval(cand))
+        logger.log('cand: {}, fid: {}'.format(cand, info['fid']))
+        info['visited'] = True
+        return True
+
+    def is_legal_before_search(self, cand):
+        return self._visit(cand)
+
+    def is_legal(self, cand):
+        return self._visit(cand)
+
+    def _fill_random(self, num, legal):
+        logger.log('random select ........')
+        while len(self.candidates) < num:
+            cand = str(self.sample_active_subnet())
+            if not legal(cand):
+                continue
+            self.candidates.append(cand)
+            logger.log('random {}/{}'.format(len(self.candidates), num))
+        logger.log('random_num = {}'.format(len(self.candidates)))
+
+    def get_random_before_search(self, num):
+        self._fill_random(num, self.is_legal_before_search)
+
+    def get_random(self, num):
+        self._fill_random(num, self.is_legal)
+
+    def get_cross(self, k, cross_num):
+        assert k in self.keep_top_k
+        logger.log('cross ......')
+        res = []
+        max_iters = cross_num * 10
+        while len(res) < cross_num and max_iters > 0:
+            max_iters -= 1
+            cand1 = eval(choice(self.keep_top_k[k]))
+            cand2 = eval(choice(self.keep_top_k[k]))
+            new_cand = [cand1[i] if np.random.random_sample() < 0.5 else cand2[i] for i in range(len(cand1))]
+            cand = str(new_cand)
+            if not self.is_legal(cand):
+                continue
+            res.append(cand)
+            logger.log('cross {}/{}'.format(len(res), cross_num))
+        logger.log('cross_num = {}'.format(len(res)))
+        return res
+
+    def _mutate(self, cand, m_prob):
+        if self.search_space is not None:
+            all_index = self.search_space
+        else:
+            all_index = range(self.base_diffusion.original_num_steps)
+        candidates = [i for i in all_index if i not in cand]
+        for i in range(len(cand)):
+            if np.random.random_sample() < m_prob:
+                new_c = random.choice(candidates)
+                del candidates[candidates.index(new_c)]
+                cand[i] = new_c
+                if len(candidates) == 0:
+                    break
+        return cand
+
+    def get_mutation(self, k, mutation_num, m_prob):
+        assert k in self.keep_top_k
+        logger.log('mutation ......')
+        res = []
+        max_iters = mutation_num * 10
+        while len(res) < mutation_num and max_iters > 0:
+            max_iters -= 1
+            cand = str(self._mutate(eval(choice(self.keep_top_k[k])), m_prob))
+            if not self.is_legal(cand):
+                continue
+            res.append(cand)
+            logger.log('mutation {}/{}'.format(len(res), mutation_num))
+        logger.log('mutation_num = {}'.format(len(res)))
+        return res
+
+    def mutate_init_x(self, x0, mutation_num, m_prob):
+        logger.log('mutation x0 ......')
+        res = []
+        max_iters = mutation_num * 10
+        while len(res) < mutation_num and max_iters > 0:
+            max_iters -= 1
+            cand = str(self._mutate(eval(x0), m_prob))
+            if not self.is_legal_before_search(cand):
+                continue
+            res.append(cand)
+            logger.log('mutation x0 {}/{}'.format(len(res), mutation_num))
+        logger.log('mutation_num = {}'.format(len(res)))
+        return res
+
+    def search(self):
+        args = self.args
+        logger.log('population_num = {} select_num = {} mutation_num = {} crossover_num = {} random_num = {} max_epochs = {}'.format(
+            self.population_num, self.select_num, self.mutation_num, self.crossover_num,
+            self.population_num - self.mutation_num - self.crossover_num, self.max_epochs))
+        if self.x0 != '':  # search_uncondition_model.py:509-512
+            self.get_random_before_search(self.population_num // 2)
+            self.candidates += self.mutate_init_x(x0=self.x0, mutation_num=self.population_num - self.population_num // 2,
+                                                  m_prob=0.05)
+        elif getattr(args, "use_ddim_init_x", False) is False:
+            self.get_random_before_search(self.population_num)
+        else:
+            steps = self.base_diffusion.original_num_steps
+            timestep_respacing = ('ddim' if args.use_ddim else '') + str(args.time_step)
+            init_x = str(list(space_timesteps(steps, timestep_respacing)))
+            self.is_legal_before_search(init_x)
+            self.candidates.append(init_x)
+            # the guided script seeds pop//2 + 1 random candidates, the unconditional one pop//2
+            extra = 0 if self.break_at_last_epoch else 1
+            self.get_random_before_search(self.population_num // 2 + extra)
+            self.candidates += self.mutate_init_x(x0=init_x, mutation_num=self.population_num - self.population_num // 2 - 1,
+                                                  m_prob=0.1)
+        while self.epoch < self.max_epochs:
+            logger.log('epoch = {}'.format(self.epoch))
+            self.update_top_k(self.candidates, k=self.select_num, key=lambda x: self.vis_dict[x]['fid'])
+            self.update_top_k(self.candidates, k=50, key=lambda x: self.vis_dict[x]['fid'])
+            logger.log('epoch = {} : top {} result'.format(self.epoch, len(self.keep_top_k[50])))
+            for i, cand in enumerate(self.keep_top_k[50]):
+                logger.log('No.{} {} fid = {}'.format(i + 1, cand, self.vis_dict[cand]['fid']))
+            if self.break_at_last_epoch and self.epoch + 1 == self.max_epochs:
+                break
+            self.candidates = self.get_mutation(self.select_num, self.mutation_num, self.m_prob)
+            self.candidates += self.get_cross(self.select_num, self.crossover_num)
+            self.get_random(self.population_num)
+            self.epoch += 1

@@ -211,6 +211,12 @@ int adm_pool_prep_bwd(const adm_bf16* dtok, adm_bf16* dact, int n, int hw, int c
  * w'[ci][co][t] = w[co][ci][taps-1-t].  out holds adm_packed_weight_elems(cin, cout, taps).     */
 int adm_pack_conv_weight_bwd(const float* w, adm_bf16* out, int cout, int cin, int taps, void* stream);
 
+/* ---------------------------------------------------------------- FID statistics (K11, A11)
+ * Streaming float64 accumulation of s1[j] += sum_n a[n][j], s2[i][j] += sum_n a[n][i]*a[n][j] over a
+ * batch of fp32 activations [n][d] (np.mean / np.cov, evaluations/evaluator_v1.py:218-221).
+ * s1 fp64 [d], s2 fp64 [d][d], zero-initialised by the caller before the first batch.        */
+int adm_fid_accumulate(const float* acts, double* s1, double* s2, int n, int d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""FID statistics: Frechet distance (product and oracle) against analytic cases and a direct scipy
+evaluation; pooled statistics over 2 ranks (gloo, CPU); GPU accumulation vs numpy float64."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+from scipy import linalg
+
+from autodiffusion_amd.fid import ActivationAccumulator, FIDStatistics, compute_statistics
+from oracle import fid as ofid
+
+
+def _spd(d, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((d, d))
+    return a @ a.T / d + 0.1 * np.eye(d)
+
+
+def test_frechet_distance_analytic_and_direct():
+    d = 16
+    mu1, mu2 = np.arange(d) / d, np.ones(d) * 0.3
+    # commuting (diagonal) covariances: tr sqrt(S1 S2) = sum sqrt(s1 s2)
+    s1, s2 = np.diag(np.linspace(0.5, 2, d)), np.diag(np.linspace(1, 3, d))
+    want = ((mu1 - mu2) ** 2).sum() + (np.sqrt(np.diag(s1)) - np.sqrt(np.diag(s2))).__pow__(2).sum()
+    for fn in (lambda: FIDStatistics(mu1, s1).frechet_distance(FIDStatistics(mu2, s2)),
+               lambda: ofid.frechet_distance(mu1, s1, mu2, s2)):
+        assert abs(fn() - want) < 1e-9
+    # general SPD pair vs an independent evaluation through the symmetric form sqrt(S1^1/2 S2 S1^1/2)
+    a, b = _spd(d, 1), _spd(d, 2)
+    ra = linalg.sqrtm(a).real
+    tr = np.trace(linalg.sqrtm(ra @ b @ ra).real)
+    want = ((mu1 - mu2) ** 2).sum() + np.trace(a) + np.trace(b) - 2 * tr
+    got = FIDStatistics(mu1, a).frechet_distance(FIDStatistics(mu2, b))
+    assert abs(got - want) < 1e-8 and abs(ofid.frechet_distance(mu1, a, mu2, b) - want) < 1e-8
+    assert abs(FIDStatistics(mu1, a).frechet_distance(FIDStatistics(mu1, a))) < 1e-6
+
+
+def test_frechet_distance_rank_deficient_product():
+    d = 8
+    v = np.zeros((d, d)); v[0, 0] = 1.0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # the singular-product branch may warn, depending on LAPACK
+        got = FIDStatistics(np.zeros(d), v).frechet_distance(FIDStatistics(np.zeros(d), np.eye(d)))
+    assert np.isfinite(got) and abs(got - (1 + d - 2)) < 1e-3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert abs(ofid.frechet_distance(np.zeros(d), v, np.zeros(d), np.eye(d)) - got) < 1e-9
+
+
+def test_compute_statistics_matches_oracle():
+    acts = np.random.default_rng(0).standard_normal((50, 12)).astype(np.float32)
+    st = compute_statistics(acts)
+    mu, sigma = ofid.statistics(acts)
+    assert np.array_equal(st.mu, mu) and np.array_equal(st.sigma, sigma)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_main(rank, world, port, d, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100)
+    acts = rng.standard_normal((37, d))            # the whole candidate's activations
+    mine = acts[rank::world]                         # image-sharded over ranks
+    acc = ActivationAccumulator(d, "cpu")
+    acc.n = len(mine)
+    acc.s1 = torch.from_numpy(mine.sum(0))
+    acc.s2 = torch.from_numpy(mine.T @ mine)
+    st = acc.statistics()
+    if rank == 0:
+        np.savez(out, mu=st.mu, sigma=st.sigma)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pooled_statistics_two_ranks_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    d, out = 6, str(tmp_path / "pooled.npz")
+    mp.spawn(_rank_main, args=(2, _free_port(), d, out), nprocs=2, join=True)
+    z = np.load(out)
+    acts = np.random.default_rng(100).standard_normal((37, d))
+    np.testing.assert_allclose(z["mu"], acts.mean(0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(z["sigma"], np.cov(acts, rowvar=False), rtol=1e-10, atol=1e-12)
+
+
+def test_accumulator_refuses_host_activations():
+    from autodiffusion_amd._lib import AdmError
+    with pytest.raises(AdmError):
+        ActivationAccumulator(4, "cpu").add(torch.zeros(3, 4))
+
+
+@pytest.mark.gpu
+def test_gpu_accumulation_matches_numpy_float64():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = 2048
+    acts = torch.randn(700, d, generator=torch.Generator().manual_seed(0)) * 0.7 + 0.2
+    acc = ActivationAccumulator(d, "cuda:0")
+    for i in range(0, 700, 256):                     # ragged last batch
+        acc.add(acts[i:i + 256].to("cuda:0"))
+    acc.add(acts[:10].to("cuda:0"), limit=0)         # arr[:num_samples] truncation
+    st = acc.statistics()
+    a64 = acts.numpy().astype(np.float64)
+    np.testing.assert_allclose(st.mu, a64.mean(0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(st.sigma, np.cov(a64, rowvar=False), rtol=1e-9, atol=1e-11)

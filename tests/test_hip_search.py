@@ -1,0 +1,90 @@
+"""GPU: the evaluate-candidate interface end to end (get_cand_fid) and full-size property checks.
+
+The Inception network is third-party and unavailable offline, so the feature extractor here is a
+fixed random projection of the uint8 image (TEST stand-in, torch ops): what is under test is the
+path around it -- seeding, arr[:num_samples] truncation, GPU statistics, Frechet distance."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import filled, plan_c64, plan_m64
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from autodiffusion_amd.classifier import EncoderUNetModel
+    from autodiffusion_amd.script_util import create_gaussian_diffusion
+    from autodiffusion_amd.unet import UNetModel
+    pm, pc = plan_m64(dynamic=True), plan_c64()
+    model = UNetModel(pm)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled(pm).items()})
+    clf = EncoderUNetModel(pc)
+    clf.load_state_dict({k: torch.from_numpy(v) for k, v in filled(pc).items()})
+    return model.to(DEV), clf.to(DEV), create_gaussian_diffusion(steps=1000, learn_sigma=True, noise_schedule="cosine")
+
+
+def test_get_cand_fid_end_to_end(monkeypatch):
+    from autodiffusion_amd import logger, search
+    from autodiffusion_amd.fid import FIDStatistics, compute_statistics
+    model, clf, diffusion = _setup()
+    lines = []
+    monkeypatch.setattr(logger, "log", lambda *a: lines.append(" ".join(map(str, a))))
+    proj = torch.randn(3 * 64 * 64, 32, generator=torch.Generator().manual_seed(5)).to(DEV) / 100.0
+    features = lambda u8: u8.reshape(u8.shape[0], -1).float() @ proj  # noqa: E731
+    args = SimpleNamespace(max_epochs=1, select_num=2, population_num=3, m_prob=0.25, crossover_num=1, mutation_num=1,
+                           batch_size=4, num_samples=10, image_size=64, use_ddim=True, clip_denoised=True,
+                           class_cond=True, classifier_scale=1.0, seed=0, time_step=4, use_ddim_init_x=True)
+    ref = FIDStatistics(np.zeros(32), np.eye(32))
+    s = search.EvolutionSearcher(args, model, diffusion, 4, classifier=clf, features=features, feature_dim=32,
+                                 ref_stats=ref)
+    cand = [153, 424, 926, 690]
+    fid = s.get_cand_fid(cand=cand, args=args)
+    assert np.isfinite(fid) and s.active_diffusion.timestep_map == sorted(cand)
+    assert lines[0] == "sampling..." and "sampling complete" in lines and lines[-1].startswith("reset_time: ")
+    assert s.get_cand_fid(cand=cand, args=args) == fid  # seeded per (seed, candidate, batch): reproducible
+    # independent recomputation: same seeds, host numpy statistics over the first num_samples images
+    import zlib
+    seed0 = (0 * 1000003 + zlib.crc32(str(cand).encode())) & 0x7FFFFFFF
+    imgs = [s._ev.sample_batch(4, seed=seed0 + 7919 * b) for b in range(3)]
+    arr = torch.cat(imgs)[:10]
+    want = compute_statistics(features(arr).double().cpu().numpy()).frechet_distance(ref)
+    assert abs(fid - want) < 1e-6 * max(1.0, abs(want))
+    # dict candidates (timesteps + per-step skip lists) go through the same interface
+    fid2 = s.get_cand_fid(cand={"timesteps": cand, "skip_layers": [[1], [], [0, 5], [2, 3]]}, args=args)
+    assert np.isfinite(fid2) and fid2 != fid
+
+
+def test_full_size_adm64_properties():
+    """BASELINE-size architecture (ADM-G ImageNet-64, 296 M parameters): size-independent properties."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import adm64_flags
+    from autodiffusion_amd.script_util import create_model_and_diffusion
+    model, diffusion = create_model_and_diffusion(**adm64_flags(class_cond=True, dynamic=True))
+    model.to(DEV).randomize_(7)
+    assert model.layer_num == 58
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 3, 64, 64, generator=g).to(DEV)
+    t = torch.tensor([926] * 6, device=DEV)
+    y = torch.randint(0, 1000, (6,), generator=g).to(DEV)
+    out = model(x, t, y)
+    assert out.shape == (6, 6, 64, 64) and torch.isfinite(out).all() and float(out.std()) > 1e-3
+    assert torch.equal(model(x, t, y), out)                           # deterministic
+    assert torch.equal(model(x[:2], t[:2], y[:2]), out[:2])           # batch-slice invariance (ragged tiles)
+    assert torch.equal(model(x[3:], t[3:], y[3:]), out[3:])
+    skipped = model(x, t, y, skip_layer=list(range(58)))              # every body bypassed: still a valid network
+    assert torch.isfinite(skipped).all() and not torch.equal(skipped, out)
+    # searched 4-step DDIM through the reference-shaped loop: uint8 NHWC batch, idempotent under a fixed seed
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    ev = CandidateEvaluator(model, diffusion, None, image_size=64, use_ddim=True, device=DEV).set_candidate([153, 424, 926, 690])
+    a, b = ev.sample_batch(5, seed=11), ev.sample_batch(5, seed=11)
+    assert a.shape == (5, 64, 64, 3) and a.dtype == torch.uint8 and torch.equal(a, b)
+    assert not torch.equal(a, ev.sample_batch(5, seed=12))

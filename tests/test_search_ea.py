@@ -1,0 +1,68 @@
+"""Host logic of the search driver: EA operators must consume random / np.random in the reference's
+order.  Golden: tests/golden/ea_trajectory.npz, recorded from the reference EvolutionSearcher under a
+synthetic fitness (capture_golden.py::cap_ea)."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+
+from autodiffusion_amd import logger, search
+from autodiffusion_amd.script_util import create_gaussian_diffusion
+from helpers import golden
+
+
+def _searcher(**over):
+    args = SimpleNamespace(max_epochs=3, select_num=4, population_num=10, m_prob=0.25, crossover_num=3,
+                           mutation_num=5, max_fid=48.0, thres=0.2, use_ddim_init_x=True, use_ddim=True,
+                           time_step=4, init_x="")
+    for k, v in over.items():
+        setattr(args, k, v)
+    base = create_gaussian_diffusion(steps=1000, learn_sigma=True, noise_schedule="cosine")
+    s = search.EvolutionSearcher(args, model=None, base_diffusion=base, time_step=args.time_step, variant="guided")
+    evaluated = []
+
+    def fitness(cand=None, args=None):
+        evaluated.append(list(cand))
+        c = np.sort(np.array(cand, dtype=np.float64))
+        return float(np.abs(c - np.array([150., 420., 690., 930.])).sum() / 10.0)
+    s.get_cand_fid = fitness
+    return s, evaluated
+
+
+def test_ea_trajectory_matches_reference(monkeypatch):
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    g = golden("ea_trajectory")
+    s, evaluated = _searcher()
+    random.seed(0)
+    np.random.seed(0)
+    s.search()
+    assert np.array_equal(np.array(evaluated), g["evaluated"])
+    assert evaluated[:3] == [[0, 250, 500, 750], [439, 621, 160, 549], [884, 283, 730, 339]]
+    assert s.candidates == g["final_candidates"].tolist()
+    assert s.keep_top_k[50] == g["top50"].tolist()
+    np.testing.assert_array_equal([s.vis_dict[c]["fid"] for c in s.keep_top_k[50]], g["top50_fid"])
+
+
+def test_visited_candidates_are_not_re_evaluated_and_log_format(monkeypatch):
+    lines = []
+    monkeypatch.setattr(logger, "log", lambda *a: lines.append(" ".join(str(x) for x in a)))
+    s, evaluated = _searcher(max_epochs=1)
+    random.seed(1)
+    np.random.seed(1)
+    s.search()
+    assert len(evaluated) == len({str(c) for c in evaluated})  # dedupe by str(cand)
+    assert s.is_legal(str(evaluated[0])) is False
+    assert any(l.startswith("epoch = 0 : top") for l in lines)
+    assert any(l.startswith("No.1 [") and " fid = " in l for l in lines)
+    assert lines[0].startswith("population_num = 10 select_num = 4 mutation_num = 5 crossover_num = 3 random_num = 2")
+
+
+def test_search_space_is_shuffled_in_place_like_the_reference(monkeypatch):
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    s, _ = _searcher()
+    s.search_space = list(range(100, 140))
+    random.seed(3)
+    first = s.sample_active_subnet()
+    assert first == s.search_space[:4] and sorted(s.search_space) == list(range(100, 140))
+    cand = s._mutate([100, 101, 102, 103], 1.0)
+    assert all(100 <= c < 140 for c in cand) and len(set(cand)) == 4
