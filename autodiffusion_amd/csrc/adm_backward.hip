@@ -19,7 +19,7 @@
 namespace {
 
 __device__ __forceinline__ float silu_grad(float z) {
-  const float s = 1.0f / (1.0f + __expf(-z));
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
   return s * (1.0f + z * (1.0f - s));
 }
 

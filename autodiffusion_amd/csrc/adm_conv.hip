@@ -26,51 +26,60 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
 constexpr int KC = 32;           // input channels per chunk (= one MFMA K)
 constexpr int ROWB = 96;         // LDS bytes per halo pixel: 64 data + 32 pad
-constexpr int HALO_MAX = 400;    // 4 images x (8+2)^2, or 1 image x (16+2)^2 = 324
 constexpr int TI_MAX = 4;
+constexpr unsigned OOB = 0x80000000u;  // buffer-load offset beyond num_records -> returns 0
 
 struct ConvK {
   const uint16_t* in0; const uint16_t* in1; const uint16_t* w; const uint16_t* res;
   const float* bias; const float* aa; const float* ab; void* out;
   int N, H, W, C0, C1, Cout;
   int TH, TW, TI, tiles_x, tiles_y;
-  int taps, prologue, out_mode;
+  int prologue, out_mode;
   int ntiles16, nblocks_n;
+  unsigned wbytes;
 };
 
-template <int BN>
-constexpr int conv_smem_bytes() { return HALO_MAX * ROWB + 2 * BN * 64 + 2 * TI_MAX * 64 * 4; }
+template <int BN, int HALO>
+constexpr int conv_smem_bytes() { return 2 * HALO * ROWB + 2 * TI_MAX * 64 * 4; }
 
-template <int WM, int WN, int TM, int TN, int OCC>
+__device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// WM x WN waves, each TM x TN tiles of 16x16; TAPS 9 (3x3 pad 1) or 1; HALO = LDS halo pixels.
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 conv_kernel(const ConvK p) {
   constexpr int NT = 64 * WM * WN;
+  constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
-  constexpr int PASSES = (HALO_MAX * 4 + NT - 1) / NT;
-  constexpr int BUNITS = BN * 4;                       // 16-byte units per weight tile
-  constexpr int BPASS = (BUNITS + NT - 1) / NT;
-  static_assert(WM * TM * 16 == 256, "pixel tile is 256");
+  constexpr int PASSES = (HALO * 4 + NT - 1) / NT;
+  constexpr int WDEPTH = 3;                            // weight fragments are fetched 2 K-steps ahead
+  constexpr int PAD = TAPS == 9 ? 1 : 0;
+  static_assert(TAPS == 1 || PASSES <= TAPS - 1, "halo passes must fit in the taps of one chunk");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const halo = smem;
-  unsigned char* const bbuf = smem + HALO_MAX * ROWB;
-  float* const abuf = reinterpret_cast<float*>(bbuf + 2 * BN * 64);
+  unsigned char* const halo = smem;                       // [2][HALO * ROWB]
+  float* const abuf = reinterpret_cast<float*>(smem + 2 * HALO * ROWB);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
   const int wm = wave / WN, wn = wave % WN;
   const int lc = lane & 15, lq = lane >> 4;
 
   const int nb = blockIdx.x % p.nblocks_n;
   const int mt = blockIdx.x / p.nblocks_n;
-  const int PAD = p.taps == 9 ? 1 : 0;
   const int HW2 = p.TW + 2 * PAD;
   const int HPI = (p.TH + 2 * PAD) * HW2;
   const int HP = p.TI * HPI;
   const int Cin = p.C0 + p.C1;
+  const int HWimg = p.H * p.W;
 
   int img0, y0, x0;
   if (p.TI == 1) {
@@ -84,9 +93,17 @@ conv_kernel(const ConvK p) {
     y0 = 0;
     x0 = 0;
   }
+  const int nimg = min(p.TI, p.N - img0);  // images of this tile that exist
+
+  // buffer descriptors over exactly the images this tile may touch: anything else reads as zero
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in0 + (long long)img0 * HWimg * p.C0), 0, nimg * HWimg * p.C0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.C1 ? p.in1 + (long long)img0 * HWimg * p.C1 : p.in0), 0, p.C1 ? nimg * HWimg * p.C1 * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
 
   // ---- halo staging geometry: 16-byte segment s = tid + pass*NT -> (halo pixel s>>2, segment s&3)
-  int pixoff[PASSES];      // global pixel index or -1 (outside the image / batch -> zero padding)
+  int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch)
   unsigned ti_pack = 0;    // image-in-tile of each pass, 4 bits each
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
@@ -95,23 +112,34 @@ conv_kernel(const ConvK p) {
     int off = -1;
     if (hp < HP) {
       const int ti = hp / HPI, rem = hp % HPI;
-      const int n = img0 + ti, y = y0 + rem / HW2 - PAD, x = x0 + rem % HW2 - PAD;
-      if (n < p.N && y >= 0 && y < p.H && x >= 0 && x < p.W) off = (n * p.H + y) * p.W + x;
+      const int y = y0 + rem / HW2 - PAD, x = x0 + rem % HW2 - PAD;
+      if (ti < nimg && y >= 0 && y < p.H && x >= 0 && x < p.W) off = (ti * p.H + y) * p.W + x;
       ti_pack |= (unsigned)ti << (4 * ps);
     }
-    pixoff[ps] = off;
+    pixrel[ps] = off;
   }
   const int seg = tid & 3;  // NT % 4 == 0 -> the same channel segment in every pass
 
   // ---- MFMA fragment addressing
-  int abase[TM];            // LDS byte offset of this lane's pixel row (+ its 16-byte k slice)
+  // LDS byte offset of a lane's pixel row = lane part (its pixel inside the 16-pixel tile, its
+  // 16-byte k slice) + a wave-uniform part per tile (TW divides 16, so a tile starts at column 0)
+  const int alane = ((lc / p.TW) * HW2 + lc % p.TW) * ROWB + lq * 16;
+  int aoff[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = (wm * TM + i) * 16 + lc;
-    const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
-    abase[i] = (ti * HPI + (rem / p.TW) * HW2 + rem % p.TW) * ROWB + lq * 16;
+    const int m0 = (wm * TM + i) * 16;
+    const int ti = m0 / (p.TH * p.TW), rem = m0 % (p.TH * p.TW);
+    aoff[i] = (ti * HPI + (rem / p.TW) * HW2) * ROWB;
   }
-  const int wbase = ((wn * TN) * 64 + lane) * 16;
+  // weight fragments go straight from the packed image (L2-resident, fragment-ordered: one 1 KB
+  // coalesced run per wave-load) into registers -- no LDS, no per-tap barrier
+  unsigned wofs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int tile = nb * (BN / 16) + wn * TN + j;
+    wofs[j] = tile < p.ntiles16 ? (unsigned)((tile * 64 + lane) * 16) : OOB;
+  }
+  const unsigned wstep = (unsigned)p.ntiles16 * 1024u;  // bytes per K-step
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -120,24 +148,14 @@ conv_kernel(const ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int chunks = Cin / KC;
-  const int nsteps = chunks * p.taps;
-  const long long wstep = (long long)p.ntiles16 * 512;  // bf16 elements per K-step in the packed image
-  const int tile0 = nb * (BN / 16);
+  const int nsteps = chunks * TAPS;
 
-  uint4 hreg[PASSES];
-  uint4 breg[BPASS];
-
-  auto load_halo = [&](int c) {
+  auto halo_load = [&](int c, int ps) -> uint4 {
     const int cc = c * KC;
-    const uint16_t* src;
-    int cs, co;
-    if (cc < p.C0) { src = p.in0; cs = p.C0; co = cc; } else { src = p.in1; cs = p.C1; co = cc - p.C0; }
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pixoff[ps] >= 0) v = *reinterpret_cast<const uint4*>(src + (long long)pixoff[ps] * cs + co + seg * 8);
-      hreg[ps] = v;
-    }
+    const bool first = cc < p.C0;
+    const int cs = first ? p.C0 : p.C1, co = first ? cc : cc - p.C0;
+    const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
+    return first ? bufload16(rs0, voff, 0) : bufload16(rs1, voff, 0);
   };
   auto stage_affine = [&](int c, int buf) {
     if (p.prologue == 0) return;
@@ -152,84 +170,105 @@ conv_kernel(const ConvK p) {
       *reinterpret_cast<float4*>(abuf + (buf * TI_MAX + ti) * 64 + (part < 8 ? 0 : 32) + (part & 7) * 4) = v;
     }
   };
-  auto write_halo = [&](int buf) {
+  auto halo_write = [&](uint4 v, int ps, int buf) {
+    const int s = tid + ps * NT;
+    const int hp = s >> 2;
+    if (hp >= HP) return;
+    if (p.prologue != 0 && pixrel[ps] >= 0) {
+      const int ti = (ti_pack >> (4 * ps)) & 15;
+      const float* ab = abuf + (buf * TI_MAX + ti) * 64 + seg * 8;
+      float a8[8], b8[8];
+      *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ab);
+      *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ab + 4);
+      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 32);
+      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 36);
+      uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int s = tid + ps * NT;
-      const int hp = s >> 2;
-      if (hp >= HP) continue;
-      uint4 v = hreg[ps];
-      if (p.prologue != 0 && pixoff[ps] >= 0) {
-        const int ti = (ti_pack >> (4 * ps)) & 15;
-        const float* ab = abuf + (buf * TI_MAX + ti) * 64 + seg * 8;
-        float a8[8], b8[8];
-        *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ab);
-        *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ab + 4);
-        *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 32);
-        *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 36);
-        uint32_t u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
-          lo = a8[2 * j] * lo + b8[2 * j];
-          hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
-          if (p.prologue == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-          u[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
-        }
-        v = make_uint4(u[0], u[1], u[2], u[3]);
+      for (int j = 0; j < 4; ++j) {
+        float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+        lo = a8[2 * j] * lo + b8[2 * j];
+        hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
+        if (p.prologue == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
+        u[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
       }
-      *reinterpret_cast<uint4*>(halo + hp * ROWB + seg * 16) = v;
+      v = make_uint4(u[0], u[1], u[2], u[3]);
     }
-  };
-  auto load_b = [&](int step) {
-    const uint16_t* src = p.w + (long long)step * wstep;
-#pragma unroll
-    for (int bp = 0; bp < BPASS; ++bp) {
-      const int u = tid + bp * NT;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (u < BUNITS && tile0 + (u >> 6) < p.ntiles16) v = *reinterpret_cast<const uint4*>(src + (long long)(tile0 * 64 + u) * 8);
-      breg[bp] = v;
-    }
-  };
-  auto write_b = [&](int buf) {
-#pragma unroll
-    for (int bp = 0; bp < BPASS; ++bp) {
-      const int u = tid + bp * NT;
-      if (u < BUNITS) *reinterpret_cast<uint4*>(bbuf + buf * (BN * 64) + u * 16) = breg[bp];
-    }
+    *reinterpret_cast<uint4*>(halo + buf * (HALO * ROWB) + hp * ROWB + seg * 16) = v;
   };
 
-  // ---- prologue
-  load_halo(0);
+  uint4 wreg[WDEPTH][TN];
+  auto load_w = [&](int step, uint4 (&dst)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) dst[j] = bufload16(rsw, wofs[j], (unsigned)step * wstep);
+  };
+
+  // ---- prologue: chunk 0 halo, weights of steps 0 and 1
   stage_affine(0, 0);
-  load_b(0);
-  write_b(0);
+  load_w(0, wreg[0]);
+  if (nsteps > 1) load_w(1, wreg[1]);
+  {
+    uint4 h0[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) h0[ps] = halo_load(0, ps);
+    __syncthreads();  // abuf[0] visible
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) halo_write(h0[ps], ps, 0);
+  }
   __syncthreads();
 
-  int step = 0;
-  for (int c = 0; c < chunks; ++c) {
-    write_halo(c & 1);
-    if (c + 1 < chunks) {
-      load_halo(c + 1);
-      stage_affine(c + 1, (c + 1) & 1);
+  auto mfma_tap = [&](const unsigned char* hp, const uint4 (&w)[TN]) {
+    const unsigned char* hl = hp + alane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {  // pixel tile outer: one activation fragment live at a time
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af, acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    for (int t = 0; t < p.taps; ++t, ++step) {
-      const bool has_next = step + 1 < nsteps;
-      if (has_next) load_b(step + 1);
-      const int tapoff = p.taps == 9 ? ((t / 3) * HW2 + (t % 3)) * ROWB : 0;
-      const unsigned char* bcur = bbuf + (step & 1) * (BN * 64) + wbase;
-      bf16x8 af[TM];
+  };
+
+  if constexpr (TAPS == 9) {
+    // 9 % WDEPTH == 0: the weight ring index of tap t is t % 3 in every chunk (static registers)
+    int step = 0;
+    for (int c = 0; c < chunks; ++c) {
+      const bool more = c + 1 < chunks;
+      const int hb = c & 1;
+      uint4 hprev = make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(halo + abase[i] + tapoff);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(bcur + j * 1024);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[i], acc[i][j], 0, 0, 0);
+      for (int t = 0; t < 9; ++t, ++step) {
+        // next chunk's halo: pass t is fetched now; pass t-1 (fetched during the previous tap) is
+        // transformed and parked in the other halo buffer
+        uint4 hcur = make_uint4(0, 0, 0, 0);
+        if (t == 0 && more) stage_affine(c + 1, hb ^ 1);
+        if (t < PASSES && more) hcur = halo_load(c + 1, t);
+        if (step + 2 < nsteps) load_w(step + 2, wreg[(t + 2) % WDEPTH]);
+        if (t == 1) __syncthreads();  // abuf[hb^1] (written at tap 0) visible to every wave
+        if (t >= 1 && t - 1 < PASSES && more) halo_write(hprev, t - 1, hb ^ 1);
+        hprev = hcur;
+        mfma_tap(halo + hb * (HALO * ROWB) + ((t / 3) * HW2 + (t % 3)) * ROWB, wreg[t % WDEPTH]);
       }
-      if (has_next) write_b((step + 1) & 1);
+      __syncthreads();  // halo[hb^1] complete; every wave is done reading halo[hb]
+    }
+  } else {
+    // 1x1: one K-step per chunk; weights one step ahead (register copy), halo double-buffered
+    for (int c = 0; c < chunks; ++c) {
+      const bool more = c + 1 < chunks;
+      const int hb = c & 1;
+      uint4 h1[PASSES];
+      if (more) {
+        stage_affine(c + 1, hb ^ 1);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) h1[ps] = halo_load(c + 1, ps);
+      }
+      if (c + 2 < chunks) load_w(c + 2, wreg[2]);
+      mfma_tap(halo + hb * (HALO * ROWB), wreg[0]);
+      if (more) {
+        __syncthreads();  // abuf[hb^1] visible
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) halo_write(h1[ps], ps, hb ^ 1);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { wreg[0][j] = wreg[1][j]; wreg[1][j] = wreg[2][j]; }
       __syncthreads();
     }
   }
@@ -296,16 +335,16 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
   }
 }
 
-template <int WM, int WN, int TM, int TN, int OCC>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
 int launch_conv(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int BN = WN * TN * 16;
-  constexpr int smem = conv_smem_bytes<BN>();
+  constexpr int smem = conv_smem_bytes<BN, HALO>();
   static bool attr_set_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   bool& attr_set = attr_set_dev[dev & 63];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
@@ -314,8 +353,44 @@ int launch_conv(const ConvK& k, int m_tiles, hipStream_t s) {
   kk.nblocks_n = (k.Cout + BN - 1) / BN;
   const long long blocks = (long long)m_tiles * kk.nblocks_n;
   ADM_REQUIRE(blocks < (1ll << 31), ADM_E_SHAPE, "adm_conv: grid too large");
-  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC>), dim3((unsigned)blocks), dim3(64 * WM * WN), smem, s, kk);
+  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO>), dim3((unsigned)blocks), dim3(64 * WM * WN), smem, s, kk);
   return adm_check_launch("adm_conv");
+}
+
+// tile geometry for a BM-pixel tile: returns false if the map does not tile
+bool conv_geometry(ConvK& k, int BM, int taps, int halo_max) {
+  k.TW = k.W < 16 ? k.W : 16;
+  k.TH = k.H < BM / k.TW ? k.H : BM / k.TW;
+  if (k.TH <= 0 || BM % (k.TH * k.TW) != 0 || k.H % k.TH != 0 || k.W % k.TW != 0) return false;
+  k.TI = BM / (k.TH * k.TW);
+  const int pad = taps == 9 ? 1 : 0;
+  if (k.TI > TI_MAX || k.TI * (k.TH + 2 * pad) * (k.TW + 2 * pad) > halo_max) return false;
+  k.tiles_x = k.W / k.TW;
+  k.tiles_y = k.H / k.TH;
+  return true;
+}
+
+template <int WM, int WN, int TM, int TN, int OCC>
+int dispatch_conv(ConvK& k, int taps, hipStream_t s) {
+  constexpr int BM = WM * TM * 16;
+  // halo capacity: one image (TH+2)(TW+2) patch, or TI images of small maps
+  if (taps == 9) {
+    if (conv_geometry(k, BM, 9, (BM == 256) ? 324 : 180) && k.TI == 1) {
+      const int m_tiles = k.N * k.tiles_x * k.tiles_y;
+      return launch_conv<WM, WN, TM, TN, OCC, 9, (BM == 256) ? 324 : 180>(k, m_tiles, s);
+    }
+    if (conv_geometry(k, BM, 9, (BM == 256) ? 400 : 200)) {
+      const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
+      return launch_conv<WM, WN, TM, TN, (BM == 256 ? 1 : OCC), 9, (BM == 256) ? 400 : 200>(k, m_tiles, s);
+    }
+  } else {
+    if (conv_geometry(k, BM, 1, BM)) {
+      const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
+      return launch_conv<WM, WN, TM, TN, OCC, 1, BM>(k, m_tiles, s);
+    }
+  }
+  ADM_FAIL(ADM_E_SHAPE, "adm_conv: %dx%d feature map does not tile into %d-pixel patches (need >= 8x8, power of two)",
+           k.H, k.W, BM);
 }
 
 }  // namespace
@@ -359,21 +434,9 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;
   k.bias = a->bias; k.aa = a->aff_a; k.ab = a->aff_b; k.out = a->out;
   k.N = a->n; k.H = a->h; k.W = a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
-  k.taps = a->taps; k.prologue = a->prologue; k.out_mode = a->out_mode;
+  k.prologue = a->prologue; k.out_mode = a->out_mode;
   k.ntiles16 = (a->cout + 15) / 16;
-  // 256-pixel patch: TW = min(W,16), TH = min(H, 256/TW); small maps batch TI images per tile
-  const int BM = 256;
-  k.TW = a->w < 16 ? a->w : 16;
-  k.TH = a->h < BM / k.TW ? a->h : BM / k.TW;
-  ADM_REQUIRE(BM % (k.TH * k.TW) == 0 && a->h % k.TH == 0 && a->w % k.TW == 0, ADM_E_SHAPE,
-              "adm_conv: %dx%d feature map does not tile into %d-pixel patches", a->h, a->w, BM);
-  k.TI = BM / (k.TH * k.TW);
-  const int pad = a->taps == 9 ? 1 : 0;
-  ADM_REQUIRE(k.TI <= TI_MAX && k.TI * (k.TH + 2 * pad) * (k.TW + 2 * pad) <= HALO_MAX, ADM_E_SHAPE,
-              "adm_conv: %dx%d feature map too small for the halo tile (need >= 8x8)", a->h, a->w);
-  k.tiles_x = a->w / k.TW;
-  k.tiles_y = a->h / k.TH;
-  const int m_tiles = k.TI == 1 ? a->n * k.tiles_x * k.tiles_y : (a->n + k.TI - 1) / k.TI;
+  k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
 
   int variant = a->variant;
@@ -385,11 +448,13 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
       variant = (w96 <= w128) ? 2 : 1;
     }
   }
+  // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
+  const bool small_map = a->h * a->w <= 64;
   switch (variant) {
-    case 1: return launch_conv<2, 2, 8, 4, 1>(k, m_tiles, s);  // 256 x 128
-    case 2: return launch_conv<2, 2, 8, 3, 2>(k, m_tiles, s);  // 256 x 96
-    case 3: return launch_conv<4, 1, 4, 1, 2>(k, m_tiles, s);  // 256 x 16 (output head)
-    case 4: return launch_conv<2, 2, 8, 2, 2>(k, m_tiles, s);  // 256 x 64
+    case 1: return small_map ? dispatch_conv<2, 2, 4, 4, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 4, 1>(k, a->taps, s);
+    case 2: return small_map ? dispatch_conv<2, 2, 4, 3, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 3, 2>(k, a->taps, s);
+    case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, s);  // 256 x 16 (output head / stem backward)
+    case 4: return small_map ? dispatch_conv<2, 2, 4, 2, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 2, 2>(k, a->taps, s);
     default: ADM_FAIL(ADM_E_ARG, "adm_conv: unknown variant %d", variant);
   }
 }

@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--workload", default="auto", choices=["auto", "guided", "unguided"])
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse N ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -88,12 +90,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    dev = torch.device(f"cuda:{local_rank}")
+    dev = torch.device(f"cuda:{local_rank % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", init_method="env://")
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     from autodiffusion_amd import ops
     from autodiffusion_amd.evaluate import CandidateEvaluator
@@ -145,7 +151,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

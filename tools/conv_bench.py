@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of adm_conv on the layer shapes that dominate ADM-G-64 at batch 256 (MI355X).
+Prints TFLOP/s (algorithmic 2*M*Cout*Cin*taps) per shape; used to iterate on csrc/adm_conv.hip."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from autodiffusion_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+SHAPES = [
+    # name, n, hw, c0, c1, cout, taps, prologue, res
+    ("unet 192->192 @64 3x3 gn+res", 256, 64, 192, 0, 192, 9, 2, True),
+    ("unet 384|192->192 @64 3x3 cat", 256, 64, 192, 192, 192, 9, 2, False),
+    ("unet 384->384 @32 3x3", 256, 32, 384, 0, 384, 9, 2, True),
+    ("unet 576->576 @16 3x3", 256, 16, 576, 0, 576, 9, 2, True),
+    ("unet 768->768 @8 3x3", 256, 8, 768, 0, 768, 9, 2, True),
+    ("unet 1536->768 @8 3x3 cat", 256, 8, 768, 768, 768, 9, 2, False),
+    ("unet qkv 384->1152 @32 1x1", 256, 32, 384, 0, 1152, 1, 1, False),
+    ("unet proj 384->384 @32 1x1", 256, 32, 384, 0, 384, 1, 0, True),
+    ("clf 128->128 @64 3x3", 256, 64, 128, 0, 128, 9, 2, True),
+    ("clf 256->256 @32 3x3", 256, 32, 256, 0, 256, 9, 2, True),
+    ("clf 512->512 @8 3x3", 256, 8, 512, 0, 512, 9, 2, True),
+    ("clf bwd 128->128 @64 raw", 256, 64, 128, 0, 128, 9, 0, False),
+]
+
+
+def main():
+    reps = int(os.environ.get("REPS", "5"))
+    variant = int(os.environ.get("VARIANT", "0"))
+    only = os.environ.get("ONLY")
+    tot_f = tot_t = 0.0
+    for name, n, hw, c0, c1, cout, taps, prologue, res in SHAPES:
+        if only and only not in name:
+            continue
+        cin = c0 + c1
+        k = 3 if taps == 9 else 1
+        x0 = (torch.randn(n, hw, hw, c0, device=DEV)).to(torch.bfloat16)
+        x1 = (torch.randn(n, hw, hw, c1, device=DEV)).to(torch.bfloat16) if c1 else None
+        w = torch.randn(cout, cin, k, k, device=DEV) * (cin * taps) ** -0.5
+        wp = ops.pack_conv_weight(w)
+        b = torch.randn(cout, device=DEV) * 0.1
+        aff = (1 + 0.1 * torch.randn(n, cin, device=DEV), 0.1 * torch.randn(n, cin, device=DEV)) if prologue else None
+        r = torch.randn(n, hw, hw, cout, device=DEV).to(torch.bfloat16) if res else None
+        out = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+        for _ in range(2):
+            ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * n * hw * hw * cout * cin * taps
+        tot_f += fl
+        tot_t += ms
+        print(f"{name:36s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s  (variant {ops.conv_variant(cout) if variant == 0 else variant})")
+    print(f"{'TOTAL':36s} {tot_t * 1e3:9.1f} us  {tot_f / tot_t / 1e9:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
