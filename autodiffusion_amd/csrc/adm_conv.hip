@@ -22,6 +22,10 @@
 //               (96-byte pixel rows: conflict-free ds_read_b128 for the 16-pixel fragment), and
 //               then reused by all 9 taps; zero padding is applied after the activation
 //   weights     one [BN x 32] tile per (chunk, tap), double-buffered in LDS, prefetched a step ahead
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "adm_common.h"
 
 namespace {
@@ -41,10 +45,16 @@ struct ConvK {
   int prologue, out_mode;
   int ntiles16, nblocks_n;
   unsigned wbytes;
+  int dbg;  // timing experiments only (ADM_CONV_DBG): 1 = no epilogue stores, 2 = no activation loads, 4 = no MFMA
 };
 
 template <int BN, int HALO>
-constexpr int conv_smem_bytes() { return 2 * HALO * ROWB + 2 * TI_MAX * 64 * 4; }
+constexpr int conv_smem_bytes_k() { return 2 * HALO * ROWB + 2 * TI_MAX * 64 * 4; }
+// the epilogue restages one wave-row of the output tile (BM/WM pixels x BN channels, bf16) in the same LDS
+template <int BN, int HALO, int RPX>
+constexpr int conv_smem_bytes() {
+  return conv_smem_bytes_k<BN, HALO>() > RPX * (BN * 2 + 16) ? conv_smem_bytes_k<BN, HALO>() : RPX * (BN * 2 + 16);
+}
 
 __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
@@ -154,7 +164,7 @@ conv_kernel(const ConvK p) {
     const int cc = c * KC;
     const bool first = cc < p.C0;
     const int cs = first ? p.C0 : p.C1, co = first ? cc : cc - p.C0;
-    const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
+    const unsigned voff = (pixrel[ps] >= 0 && !(p.dbg & 2)) ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
     return first ? bufload16(rs0, voff, 0) : bufload16(rs1, voff, 0);
   };
   auto stage_affine = [&](int c, int buf) {
@@ -204,6 +214,7 @@ conv_kernel(const ConvK p) {
 
   // ---- prologue: chunk 0 halo, weights of steps 0 and 1
   stage_affine(0, 0);
+  if (TAPS == 1 && chunks > 1) stage_affine(1, 1);
   load_w(0, wreg[0]);
   if (nsteps > 1) load_w(1, wreg[1]);
   {
@@ -221,6 +232,7 @@ conv_kernel(const ConvK p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {  // pixel tile outer: one activation fragment live at a time
       const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
+      if (p.dbg & 4) { asm volatile("" :: "v"(af)); continue; }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af, acc[i][j], 0, 0, 0);
@@ -250,67 +262,116 @@ conv_kernel(const ConvK p) {
       __syncthreads();  // halo[hb^1] complete; every wave is done reading halo[hb]
     }
   } else {
-    // 1x1: one K-step per chunk; weights one step ahead (register copy), halo double-buffered
-    for (int c = 0; c < chunks; ++c) {
-      const bool more = c + 1 < chunks;
-      const int hb = c & 1;
-      uint4 h1[PASSES];
-      if (more) {
-        stage_affine(c + 1, hb ^ 1);
+    // 1x1: one K-step (24 MFMAs per wave) per chunk, so HBM/L2 latency must be covered by depth, not by
+    // the taps: activation segments are fetched 2 chunks ahead (register ring of 2), weight fragments
+    // 3 chunks ahead (ring of 4); one barrier per chunk.  The loop is unrolled by 4 so that every ring
+    // slot is a compile-time register.
+    uint4 ring[2][PASSES];
+    uint4 wq[4][TN];
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) h1[ps] = halo_load(c + 1, ps);
+    for (int j = 0; j < TN; ++j) { wq[0][j] = wreg[0][j]; wq[1][j] = wreg[1][j]; }
+    if (chunks > 2) load_w(2, wq[2]);
+    if (chunks > 1) {
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(1, ps);
+    }
+    auto body = [&](int c, auto sa_, auto sw_) {
+      constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
+      if (c >= chunks) return;
+      if (c + 2 < chunks) {
+        stage_affine(c + 2, c & 1);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c + 2, ps);
       }
-      if (c + 2 < chunks) load_w(c + 2, wreg[2]);
-      mfma_tap(halo + hb * (HALO * ROWB), wreg[0]);
-      if (more) {
-        __syncthreads();  // abuf[hb^1] visible
+      if (c + 3 < chunks) load_w(c + 3, wq[(SW + 3) % 4]);
+      mfma_tap(halo + (c & 1) * (HALO * ROWB), wq[SW]);
+      if (c + 1 < chunks) {
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) halo_write(h1[ps], ps, hb ^ 1);
+        for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) { wreg[0][j] = wreg[1][j]; wreg[1][j] = wreg[2][j]; }
       __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    for (int c0 = 0; c0 < chunks; c0 += 4) {
+      body(c0, I0{}, I0{});
+      body(c0 + 1, I1{}, I1{});
+      body(c0 + 2, I0{}, I2{});
+      body(c0 + 3, I1{}, I3{});
     }
   }
 
   // ---- epilogue: lane (lc, lq) holds channels 4*lq..4*lq+3 of tile j for pixel lc of tile i
+  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+  if (p.out_mode == 0) {
+    // bf16 NHWC: per wave-row of the tile, stage (acc + bias) as bf16 in LDS, then write whole pixel rows
+    // with 16-byte lanes (BN*2 contiguous bytes per pixel) and add the residual with equally coalesced
+    // loads -- fragment-shaped 8-byte stores touch 16 cache lines per instruction and dominated 1x1 convs
+    constexpr int RPX = TM * 16;            // pixels per round (= one wm row of waves)
+    constexpr int EROW = BN * 2 + 16;       // staged bytes per pixel
+    constexpr int SEGS = BN / 8;            // 16-byte segments per pixel
+    uint16_t* const outp = reinterpret_cast<uint16_t*>(p.out);
+    for (int r = 0; r < WM; ++r) {
+      __syncthreads();
+      if (wm == r) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int ch0 = (wn * TN + j) * 16 + lq * 4;
+          const int gch = nb * BN + ch0;
+          float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gch + 3 < p.Cout) bs = *reinterpret_cast<const float4*>(p.bias + gch);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            uint2 o;
+            o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0] + bs.x) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1] + bs.y) << 16);
+            o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2] + bs.z) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3] + bs.w) << 16);
+            *reinterpret_cast<uint2*>(smem + (i * 16 + lc) * EROW + ch0 * 2) = o;
+          }
+        }
+      }
+      __syncthreads();
+      for (int u = tid; u < RPX * SEGS; u += NT) {
+        const int pl = u / SEGS, sg = u % SEGS;
+        const int gch = nb * BN + sg * 8;
+        if (gch >= p.Cout) continue;
+        const int m = r * RPX + pl;
+        const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
+        const int n = img0 + ti;
+        if (n >= p.N) continue;
+        const long long pix = ((long long)n * p.H + y0 + rem / p.TW) * p.W + x0 + rem % p.TW;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + pl * EROW + sg * 16);
+        if (p.res) {
+          const uint4 rr = *reinterpret_cast<const uint4*>(p.res + pix * p.Cout + gch);
+          uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+          const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
+            const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
+            a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+          }
+          v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+        }
+        *reinterpret_cast<uint4*>(outp + pix * p.Cout + gch) = v;
+      }
+    }
+    return;
+  }
+  // fp32 NCHW (output head / stem backward): few channels, direct stores
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = (wm * TM + i) * 16 + lc;
     const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
     const int n = img0 + ti, y = y0 + rem / p.TW, x = x0 + rem % p.TW;
     if (n >= p.N) continue;
-    const long long pix = ((long long)n * p.H + y) * p.W + x;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int ch0 = nb * BN + (wn * TN + j) * 16 + lq * 4;
-      if (ch0 >= p.Cout) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.out_mode == 0 && ch0 + 3 < p.Cout) {
-        const float4 bs = *reinterpret_cast<const float4*>(p.bias + ch0);
-        v[0] += bs.x; v[1] += bs.y; v[2] += bs.z; v[3] += bs.w;
-        if (p.res) {
-          const uint2 r = *reinterpret_cast<const uint2*>(p.res + pix * p.Cout + ch0);
-          v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-          v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = (uint32_t)adm_f32_to_bf16(v[0]) | ((uint32_t)adm_f32_to_bf16(v[1]) << 16);
-        o.y = (uint32_t)adm_f32_to_bf16(v[2]) | ((uint32_t)adm_f32_to_bf16(v[3]) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + pix * p.Cout + ch0) = o;
-      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int ch = ch0 + e;
-          if (ch >= p.Cout) continue;
-          float r = v[e] + p.bias[ch];
-          if (p.out_mode == 0) {
-            if (p.res) r += adm_bf16_to_f32(p.res[pix * p.Cout + ch]);
-            reinterpret_cast<uint16_t*>(p.out)[pix * p.Cout + ch] = adm_f32_to_bf16(r);
-          } else {
-            reinterpret_cast<float*>(p.out)[(((long long)n * p.Cout + ch) * p.H + y) * p.W + x] = r;
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int ch = ch0 + e;
+        if (ch >= p.Cout) continue;
+        reinterpret_cast<float*>(p.out)[(((long long)n * p.Cout + ch) * p.H + y) * p.W + x] = acc[i][j][e] + p.bias[ch];
       }
     }
   }
@@ -338,7 +399,7 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
 template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
 int launch_conv(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int BN = WN * TN * 16;
-  constexpr int smem = conv_smem_bytes<BN, HALO>();
+  constexpr int smem = conv_smem_bytes<BN, HALO, TM * 16>();
   static bool attr_set_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -431,6 +492,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE((long long)a->n * a->h * a->w < (1ll << 31) / 4, ADM_E_SHAPE, "adm_conv: too many pixels for 32-bit index");
 
   ConvK k{};
+  { static const char* e = getenv("ADM_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
   k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;
   k.bias = a->bias; k.aa = a->aff_a; k.ab = a->aff_b; k.out = a->out;
   k.N = a->n; k.H = a->h; k.W = a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
@@ -439,14 +501,19 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
 
+  // tiling variant (output-tile width): 5 = 192 (8 waves), 1 = 128, 2 = 96, 4 = 64, 3 = 16 (4 waves).
+  // Measured on MI355X (tools/conv_bench.py): the 8-wave 192-wide tile shares one halo staging + prologue
+  // transform among twice as many MFMAs and wins whenever it pads <= 10 %; otherwise the 96-wide tile is
+  // the fastest per useful column unless it pads > 15 % (then 64-wide); on the 128-pixel tiles of 8x8
+  // maps the 128-wide tile wins when it pads no more than the 96-wide one.
   int variant = a->variant;
   if (variant == 0) {
+    const int w192 = ((a->cout + 191) / 192) * 192, w128 = ((a->cout + 127) / 128) * 128;
+    const int w96 = ((a->cout + 95) / 96) * 96, w64 = ((a->cout + 63) / 64) * 64;
     if (a->cout <= 16) variant = 3;
-    else if (a->cout <= 64) variant = 4;
-    else {
-      const int w128 = ((a->cout + 127) / 128) * 128, w96 = ((a->cout + 95) / 96) * 96;
-      variant = (w96 <= w128) ? 2 : 1;
-    }
+    else if (w192 * 10 <= a->cout * 11) variant = 5;
+    else if (a->h * a->w <= 64) variant = (w128 <= w96) ? 1 : 2;
+    else variant = (w96 * 0.85 <= w64) ? 2 : 4;
   }
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
   const bool small_map = a->h * a->w <= 64;
@@ -455,6 +522,8 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     case 2: return small_map ? dispatch_conv<2, 2, 4, 3, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 3, 2>(k, a->taps, s);
     case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, s);  // 256 x 16 (output head / stem backward)
     case 4: return small_map ? dispatch_conv<2, 2, 4, 2, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 2, 2>(k, a->taps, s);
+    // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs
+    case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, s);
     default: ADM_FAIL(ADM_E_ARG, "adm_conv: unknown variant %d", variant);
   }
 }

@@ -19,18 +19,21 @@ BF16 = torch.bfloat16
 GN_EPS = 1e-5
 
 # bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
-# every conv launch appends (start_event, end_event, algorithmic_flops, variant).
+# every conv launch appends (start_event, end_event, algorithmic_flops, (variant, taps, big_map)).
 CONV_PROFILE = None
 
 
-def conv_variant(cout: int) -> int:
-    """Tiling variant picked for an output-channel count (mirrors adm_conv's auto rule)."""
+def conv_variant(cout: int, hw: int) -> int:
+    """Tiling variant picked for an output-channel count and map size (mirrors adm_conv's auto rule)."""
+    w192, w128 = -(-cout // 192) * 192, -(-cout // 128) * 128
+    w96, w64 = -(-cout // 96) * 96, -(-cout // 64) * 64
     if cout <= 16:
         return 3
-    if cout <= 64:
-        return 4
-    w128, w96 = -(-cout // 128) * 128, -(-cout // 96) * 96
-    return 2 if w96 <= w128 else 1
+    if w192 * 10 <= cout * 11:
+        return 5
+    if hw <= 64:
+        return 1 if w128 <= w96 else 2
+    return 2 if w96 * 0.85 <= w64 else 4
 
 
 def _stream() -> int:
@@ -199,14 +202,14 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.out = _ptr(out)
     a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, c1, cout
     if variant == 0:
-        variant = conv_variant(cout)
+        variant = conv_variant(cout, h * w)
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
         e1.record()
-        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, variant))
+        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64)))
         return out
     check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
     return out

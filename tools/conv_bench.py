@@ -31,10 +31,13 @@ def main():
     reps = int(os.environ.get("REPS", "5"))
     variant = int(os.environ.get("VARIANT", "0"))
     only = os.environ.get("ONLY")
+    force_raw = os.environ.get("RAW") == "1"
     tot_f = tot_t = 0.0
     for name, n, hw, c0, c1, cout, taps, prologue, res in SHAPES:
         if only and only not in name:
             continue
+        if force_raw:
+            prologue = 0
         cin = c0 + c1
         k = 3 if taps == 9 else 1
         x0 = (torch.randn(n, hw, hw, c0, device=DEV)).to(torch.bfloat16)
@@ -58,7 +61,7 @@ def main():
         fl = 2.0 * n * hw * hw * cout * cin * taps
         tot_f += fl
         tot_t += ms
-        print(f"{name:36s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s  (variant {ops.conv_variant(cout) if variant == 0 else variant})")
+        print(f"{name:36s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s  (variant {ops.conv_variant(cout, hw * hw) if variant == 0 else variant})")
     print(f"{'TOTAL':36s} {tot_t * 1e3:9.1f} us  {tot_f / tot_t / 1e9:8.1f} TFLOP/s")
 
 
