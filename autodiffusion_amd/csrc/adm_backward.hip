@@ -47,8 +47,10 @@ gn_bwd_partial_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
   if (lane < lanes) {
     const int ch = g8 * 8;
     float a8[8], b8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a8[j] = aa[(long long)img * c + ch + j]; b8[j] = ab[(long long)img * c + ch + j]; }
+    *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(aa + (long long)img * c + ch);
+    *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(aa + (long long)img * c + ch + 4);
+    *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + (long long)img * c + ch);
+    *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + (long long)img * c + ch + 4);
     for (int p = p_begin + lane; p < p_end; p += lanes) {
       const uint4 xv = *reinterpret_cast<const uint4*>(x + ((long long)img * hw + p) * c + ch);
       const uint4 gv = *reinterpret_cast<const uint4*>(dy + src_pixel(dy_mode, img, p / w, p % w, h, w) * c + ch);
@@ -134,17 +136,25 @@ gn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__
     uint4 av = make_uint4(0, 0, 0, 0);
     if (add) av = *reinterpret_cast<const uint4*>(add + src_pixel(add_mode, img, py, px, h, w) * c + ch);
     const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w}, au[4] = {av.x, av.y, av.z, av.w};
-    float r[8];
+    float r[8], a8[8], b8[8], k18[8], k08[8];
+    const long long cb = (long long)img * c + ch;
+    *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(aa + cb);
+    *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(aa + cb + 4);
+    *reinterpret_cast<float4*>(k18) = *reinterpret_cast<const float4*>(k1 + cb);
+    *reinterpret_cast<float4*>(k18 + 4) = *reinterpret_cast<const float4*>(k1 + cb + 4);
+    *reinterpret_cast<float4*>(k08) = *reinterpret_cast<const float4*>(k0 + cb);
+    *reinterpret_cast<float4*>(k08 + 4) = *reinterpret_cast<const float4*>(k0 + cb + 4);
+    if (silu) {
+      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + cb);
+      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + cb + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const uint32_t sh = (j & 1) ? 0u : 16u;
-      const float xx = (j & 1) ? __uint_as_float(xu[j >> 1] & 0xffff0000u) : __uint_as_float(xu[j >> 1] << sh);
-      float gg = ((j & 1) ? __uint_as_float(gu[j >> 1] & 0xffff0000u) : __uint_as_float(gu[j >> 1] << sh)) * dys;
-      const float ad = ((j & 1) ? __uint_as_float(au[j >> 1] & 0xffff0000u) : __uint_as_float(au[j >> 1] << sh)) * adds;
-      const long long ci = (long long)img * c + ch + j;
-      const float a = aa[ci];
-      if (silu) gg *= silu_grad(a * xx + ab[ci]);
-      r[j] = a * gg + k1[ci] * xx + k0[ci] + ad;
+      const float xx = (j & 1) ? __uint_as_float(xu[j >> 1] & 0xffff0000u) : __uint_as_float(xu[j >> 1] << 16);
+      float gg = ((j & 1) ? __uint_as_float(gu[j >> 1] & 0xffff0000u) : __uint_as_float(gu[j >> 1] << 16)) * dys;
+      const float ad = ((j & 1) ? __uint_as_float(au[j >> 1] & 0xffff0000u) : __uint_as_float(au[j >> 1] << 16)) * adds;
+      if (silu) gg *= silu_grad(a8[j] * xx + b8[j]);
+      r[j] = a8[j] * gg + k18[j] * xx + k08[j] + ad;
     }
     uint4 pk;
     pk.x = adm_f32_to_bf16(r[0]) | ((uint32_t)adm_f32_to_bf16(r[1]) << 16);

@@ -42,18 +42,20 @@ struct ConvK {
   const float* bias; const float* aa; const float* ab; void* out;
   int N, H, W, C0, C1, Cout;
   int TH, TW, TI, tiles_x, tiles_y;
-  int prologue, out_mode;
+  int out_mode;
   int ntiles16, nblocks_n;
   unsigned wbytes;
-  int dbg;  // timing experiments only (ADM_CONV_DBG): 1 = no epilogue stores, 2 = no activation loads, 4 = no MFMA
 };
 
-template <int BN, int HALO>
-constexpr int conv_smem_bytes_k() { return 2 * HALO * ROWB + 2 * TI_MAX * 64 * 4; }
+// every lane of every staging pass owns an LDS slot: the halo capacity is rounded up to whole passes
+template <int NT, int HALO>
+constexpr int halo_slots() { return ((HALO * 4 + NT - 1) / NT) * NT / 4; }
+template <int NT, int HALO>
+constexpr int conv_smem_bytes_k() { return 2 * halo_slots<NT, HALO>() * ROWB + 2 * TI_MAX * 64 * 4; }
 // the epilogue restages one wave-row of the output tile (BM/WM pixels x BN channels, bf16) in the same LDS
-template <int BN, int HALO, int RPX>
+template <int NT, int BN, int HALO, int RPX>
 constexpr int conv_smem_bytes() {
-  return conv_smem_bytes_k<BN, HALO>() > RPX * (BN * 2 + 16) ? conv_smem_bytes_k<BN, HALO>() : RPX * (BN * 2 + 16);
+  return conv_smem_bytes_k<NT, HALO>() > RPX * (BN * 2 + 16) ? conv_smem_bytes_k<NT, HALO>() : RPX * (BN * 2 + 16);
 }
 
 __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -61,21 +63,23 @@ __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned vo
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-// WM x WN waves, each TM x TN tiles of 16x16; TAPS 9 (3x3 pad 1) or 1; HALO = LDS halo pixels.
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
+// WM x WN waves, each TM x TN tiles of 16x16; TAPS 9 (3x3 pad 1) or 1; HALO = halo pixels of the tile;
+// PRO = prologue (0 raw, 1 affine, 2 affine + SiLU).  Everything the inner loop branches on is a
+// template parameter: a K-step is one straight-line block (1 halo load, 1 halo transform + LDS write,
+// TN weight loads, TM LDS reads, TM*TN MFMAs) that the scheduler can software-pipeline.
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 conv_kernel(const ConvK p) {
   constexpr int NT = 64 * WM * WN;
-  constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
   constexpr int PASSES = (HALO * 4 + NT - 1) / NT;
-  constexpr int WDEPTH = 3;                            // weight fragments are fetched 2 K-steps ahead
+  constexpr int HSLOT = halo_slots<NT, HALO>();
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   static_assert(TAPS == 1 || PASSES <= TAPS - 1, "halo passes must fit in the taps of one chunk");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const halo = smem;                       // [2][HALO * ROWB]
-  float* const abuf = reinterpret_cast<float*>(smem + 2 * HALO * ROWB);
+  unsigned char* const halo = smem;                       // [2][HSLOT * ROWB]
+  float* const abuf = reinterpret_cast<float*>(smem + 2 * HSLOT * ROWB);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -113,7 +117,7 @@ conv_kernel(const ConvK p) {
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
 
   // ---- halo staging geometry: 16-byte segment s = tid + pass*NT -> (halo pixel s>>2, segment s&3)
-  int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch)
+  int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch / spare slot)
   unsigned ti_pack = 0;    // image-in-tile of each pass, 4 bits each
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
@@ -129,6 +133,7 @@ conv_kernel(const ConvK p) {
     pixrel[ps] = off;
   }
   const int seg = tid & 3;  // NT % 4 == 0 -> the same channel segment in every pass
+  const int hslot = (tid >> 2) * ROWB + seg * 16;  // LDS byte offset of pass 0's slot; pass ps adds ps*(NT/4)*ROWB
 
   // ---- MFMA fragment addressing
   // LDS byte offset of a lane's pixel row = lane part (its pixel inside the 16-pixel tile, its
@@ -158,33 +163,30 @@ conv_kernel(const ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int chunks = Cin / KC;
-  const int nsteps = chunks * TAPS;
+  const int c0chunks = p.C0 / KC;
 
+  // activation segment `ps` of chunk c (the descriptor select is scalar; out-of-image lanes read zero)
   auto halo_load = [&](int c, int ps) -> uint4 {
-    const int cc = c * KC;
-    const bool first = cc < p.C0;
-    const int cs = first ? p.C0 : p.C1, co = first ? cc : cc - p.C0;
-    const unsigned voff = (pixrel[ps] >= 0 && !(p.dbg & 2)) ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
-    return first ? bufload16(rs0, voff, 0) : bufload16(rs1, voff, 0);
+    const bool first = c < c0chunks;
+    const int cs = first ? p.C0 : p.C1, co = (first ? c : c - c0chunks) * KC;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
+    return bufload16(rs, voff, 0);
   };
   auto stage_affine = [&](int c, int buf) {
-    if (p.prologue == 0) return;
-    if (tid < p.TI * 16) {
-      const int ti = tid >> 4, part = tid & 15;
-      const int n = img0 + ti;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.N) {
+    if constexpr (PRO != 0) {
+      if (tid < p.TI * 16) {
+        const int ti = tid >> 4, part = tid & 15;
+        const int n = min(img0 + ti, p.N - 1);
         const float* s = (part < 8 ? p.aa : p.ab) + (long long)n * Cin + c * KC + (part & 7) * 4;
-        v = *reinterpret_cast<const float4*>(s);
+        *reinterpret_cast<float4*>(abuf + (buf * TI_MAX + ti) * 64 + (part < 8 ? 0 : 32) + (part & 7) * 4) =
+            *reinterpret_cast<const float4*>(s);
       }
-      *reinterpret_cast<float4*>(abuf + (buf * TI_MAX + ti) * 64 + (part < 8 ? 0 : 32) + (part & 7) * 4) = v;
     }
   };
+  // transform (fp32 affine [+ SiLU], rounded to bf16) and park a segment; zero padding stays exactly zero
   auto halo_write = [&](uint4 v, int ps, int buf) {
-    const int s = tid + ps * NT;
-    const int hp = s >> 2;
-    if (hp >= HP) return;
-    if (p.prologue != 0 && pixrel[ps] >= 0) {
+    if constexpr (PRO != 0) {
       const int ti = (ti_pack >> (4 * ps)) & 15;
       const float* ab = abuf + (buf * TI_MAX + ti) * 64 + seg * 8;
       float a8[8], b8[8];
@@ -193,30 +195,38 @@ conv_kernel(const ConvK p) {
       *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 32);
       *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 36);
       uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      const bool valid = pixrel[ps] >= 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
         lo = a8[2 * j] * lo + b8[2 * j];
         hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
-        if (p.prologue == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-        u[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
+        const uint32_t pk = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        u[j] = valid ? pk : 0u;
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
     }
-    *reinterpret_cast<uint4*>(halo + buf * (HALO * ROWB) + hp * ROWB + seg * 16) = v;
+    *reinterpret_cast<uint4*>(halo + buf * (HSLOT * ROWB) + ps * (NT / 4) * ROWB + hslot) = v;
   };
-
-  uint4 wreg[WDEPTH][TN];
   auto load_w = [&](int step, uint4 (&dst)[TN]) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) dst[j] = bufload16(rsw, wofs[j], (unsigned)step * wstep);
   };
+  auto mfma_tap = [&](const unsigned char* hp, const uint4 (&w)[TN]) {
+    const unsigned char* hl = hp + alane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {  // pixel tile outer: one activation fragment live at a time
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af, acc[i][j], 0, 0, 0);
+    }
+  };
 
-  // ---- prologue: chunk 0 halo, weights of steps 0 and 1
+  // ---- prologue: chunk 0 halo (and the affine table of chunk 1 for the 1x1 pipeline)
   stage_affine(0, 0);
   if (TAPS == 1 && chunks > 1) stage_affine(1, 1);
-  load_w(0, wreg[0]);
-  if (nsteps > 1) load_w(1, wreg[1]);
   {
     uint4 h0[PASSES];
 #pragma unroll
@@ -225,70 +235,64 @@ conv_kernel(const ConvK p) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) halo_write(h0[ps], ps, 0);
   }
-  __syncthreads();
-
-  auto mfma_tap = [&](const unsigned char* hp, const uint4 (&w)[TN]) {
-    const unsigned char* hl = hp + alane;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {  // pixel tile outer: one activation fragment live at a time
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
-      if (p.dbg & 4) { asm volatile("" :: "v"(af)); continue; }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af, acc[i][j], 0, 0, 0);
-    }
-  };
 
   if constexpr (TAPS == 9) {
-    // 9 % WDEPTH == 0: the weight ring index of tap t is t % 3 in every chunk (static registers)
-    int step = 0;
-    for (int c = 0; c < chunks; ++c) {
-      const bool more = c + 1 < chunks;
+    // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
+    uint4 wreg[3][TN];
+    load_w(0, wreg[0]);
+    load_w(1, wreg[1]);
+    __syncthreads();
+    auto chunk = [&](int c, auto more_) {
+      constexpr bool MORE = decltype(more_)::value;
       const int hb = c & 1;
+      const int step0 = c * 9;
       uint4 hprev = make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 9; ++t, ++step) {
+      for (int t = 0; t < 9; ++t) {
         // next chunk's halo: pass t is fetched now; pass t-1 (fetched during the previous tap) is
         // transformed and parked in the other halo buffer
         uint4 hcur = make_uint4(0, 0, 0, 0);
-        if (t == 0 && more) stage_affine(c + 1, hb ^ 1);
-        if (t < PASSES && more) hcur = halo_load(c + 1, t);
-        if (step + 2 < nsteps) load_w(step + 2, wreg[(t + 2) % WDEPTH]);
+        if constexpr (MORE) {
+          if (t == 0) stage_affine(c + 1, hb ^ 1);
+          if (t < PASSES) hcur = halo_load(c + 1, t);
+        }
+        if (MORE || t + 2 < 9) load_w(step0 + t + 2, wreg[(t + 2) % 3]);
         if (t == 1) __syncthreads();  // abuf[hb^1] (written at tap 0) visible to every wave
-        if (t >= 1 && t - 1 < PASSES && more) halo_write(hprev, t - 1, hb ^ 1);
+        if constexpr (MORE) {
+          if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
+        }
         hprev = hcur;
-        mfma_tap(halo + hb * (HALO * ROWB) + ((t / 3) * HW2 + (t % 3)) * ROWB, wreg[t % WDEPTH]);
+        mfma_tap(halo + hb * (HSLOT * ROWB) + ((t / 3) * HW2 + (t % 3)) * ROWB, wreg[t % 3]);
       }
       __syncthreads();  // halo[hb^1] complete; every wave is done reading halo[hb]
-    }
+    };
+    for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
+    chunk(chunks - 1, std::false_type{});
   } else {
-    // 1x1: one K-step (24 MFMAs per wave) per chunk, so HBM/L2 latency must be covered by depth, not by
-    // the taps: activation segments are fetched 2 chunks ahead (register ring of 2), weight fragments
+    // 1x1: one K-step (TM*TN MFMAs per wave) per chunk, so HBM/L2 latency must be covered by depth, not
+    // by the taps: activation segments are fetched 2 chunks ahead (register ring of 2), weight fragments
     // 3 chunks ahead (ring of 4); one barrier per chunk.  The loop is unrolled by 4 so that every ring
-    // slot is a compile-time register.
+    // slot is a compile-time register; indices past the last chunk are clamped (harmless re-reads).
     uint4 ring[2][PASSES];
     uint4 wq[4][TN];
+    const int last = chunks - 1;
+    load_w(0, wq[0]);
+    load_w(min(1, last), wq[1]);
+    load_w(min(2, last), wq[2]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { wq[0][j] = wreg[0][j]; wq[1][j] = wreg[1][j]; }
-    if (chunks > 2) load_w(2, wq[2]);
-    if (chunks > 1) {
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(1, ps);
-    }
+    for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(1, last), ps);
+    __syncthreads();
     auto body = [&](int c, auto sa_, auto sw_) {
       constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
-      if (c >= chunks) return;
-      if (c + 2 < chunks) {
-        stage_affine(c + 2, c & 1);
+      if (c > last) return;
+      const int c2 = min(c + 2, last);
+      stage_affine(c2, c & 1);
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c + 2, ps);
-      }
-      if (c + 3 < chunks) load_w(c + 3, wq[(SW + 3) % 4]);
-      mfma_tap(halo + (c & 1) * (HALO * ROWB), wq[SW]);
-      if (c + 1 < chunks) {
+      for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
+      load_w(min(c + 3, last), wq[(SW + 3) % 4]);
+      mfma_tap(halo + (c & 1) * (HSLOT * ROWB), wq[SW]);
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
-      }
+      for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
       __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -302,7 +306,6 @@ conv_kernel(const ConvK p) {
   }
 
   // ---- epilogue: lane (lc, lq) holds channels 4*lq..4*lq+3 of tile j for pixel lc of tile i
-  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   if (p.out_mode == 0) {
     // bf16 NHWC: per wave-row of the tile, stage (acc + bias) as bf16 in LDS, then write whole pixel rows
     // with 16-byte lanes (BN*2 contiguous bytes per pixel) and add the residual with equally coalesced
@@ -396,16 +399,16 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
   }
 }
 
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
-int launch_conv(const ConvK& k, int m_tiles, hipStream_t s) {
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
+int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int BN = WN * TN * 16;
-  constexpr int smem = conv_smem_bytes<BN, HALO, TM * 16>();
+  constexpr int smem = conv_smem_bytes<64 * WM * WN, BN, HALO, TM * 16>();
   static bool attr_set_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   bool& attr_set = attr_set_dev[dev & 63];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
@@ -414,8 +417,17 @@ int launch_conv(const ConvK& k, int m_tiles, hipStream_t s) {
   kk.nblocks_n = (k.Cout + BN - 1) / BN;
   const long long blocks = (long long)m_tiles * kk.nblocks_n;
   ADM_REQUIRE(blocks < (1ll << 31), ADM_E_SHAPE, "adm_conv: grid too large");
-  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO>), dim3((unsigned)blocks), dim3(64 * WM * WN), smem, s, kk);
+  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>), dim3((unsigned)blocks), dim3(64 * WM * WN), smem, s, kk);
   return adm_check_launch("adm_conv");
+}
+
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
+int launch_conv(const ConvK& k, int prologue, int m_tiles, hipStream_t s) {
+  switch (prologue) {
+    case 0: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 0>(k, m_tiles, s);
+    case 1: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 1>(k, m_tiles, s);
+    default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2>(k, m_tiles, s);
+  }
 }
 
 // tile geometry for a BM-pixel tile: returns false if the map does not tile
@@ -432,22 +444,22 @@ bool conv_geometry(ConvK& k, int BM, int taps, int halo_max) {
 }
 
 template <int WM, int WN, int TM, int TN, int OCC>
-int dispatch_conv(ConvK& k, int taps, hipStream_t s) {
+int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
   constexpr int BM = WM * TM * 16;
   // halo capacity: one image (TH+2)(TW+2) patch, or TI images of small maps
   if (taps == 9) {
     if (conv_geometry(k, BM, 9, (BM == 256) ? 324 : 180) && k.TI == 1) {
       const int m_tiles = k.N * k.tiles_x * k.tiles_y;
-      return launch_conv<WM, WN, TM, TN, OCC, 9, (BM == 256) ? 324 : 180>(k, m_tiles, s);
+      return launch_conv<WM, WN, TM, TN, OCC, 9, (BM == 256) ? 324 : 180>(k, prologue, m_tiles, s);
     }
     if (conv_geometry(k, BM, 9, (BM == 256) ? 400 : 200)) {
       const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
-      return launch_conv<WM, WN, TM, TN, (BM == 256 ? 1 : OCC), 9, (BM == 256) ? 400 : 200>(k, m_tiles, s);
+      return launch_conv<WM, WN, TM, TN, (BM == 256 ? 1 : OCC), 9, (BM == 256) ? 400 : 200>(k, prologue, m_tiles, s);
     }
   } else {
     if (conv_geometry(k, BM, 1, BM)) {
       const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
-      return launch_conv<WM, WN, TM, TN, OCC, 1, BM>(k, m_tiles, s);
+      return launch_conv<WM, WN, TM, TN, OCC, 1, BM>(k, prologue, m_tiles, s);
     }
   }
   ADM_FAIL(ADM_E_SHAPE, "adm_conv: %dx%d feature map does not tile into %d-pixel patches (need >= 8x8, power of two)",
@@ -492,11 +504,10 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE((long long)a->n * a->h * a->w < (1ll << 31) / 4, ADM_E_SHAPE, "adm_conv: too many pixels for 32-bit index");
 
   ConvK k{};
-  { static const char* e = getenv("ADM_CONV_DBG"); k.dbg = e ? atoi(e) : 0; }
   k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;
   k.bias = a->bias; k.aa = a->aff_a; k.ab = a->aff_b; k.out = a->out;
   k.N = a->n; k.H = a->h; k.W = a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
-  k.prologue = a->prologue; k.out_mode = a->out_mode;
+  k.out_mode = a->out_mode;
   k.ntiles16 = (a->cout + 15) / 16;
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
@@ -518,12 +529,12 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
   const bool small_map = a->h * a->w <= 64;
   switch (variant) {
-    case 1: return small_map ? dispatch_conv<2, 2, 4, 4, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 4, 1>(k, a->taps, s);
-    case 2: return small_map ? dispatch_conv<2, 2, 4, 3, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 3, 2>(k, a->taps, s);
-    case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, s);  // 256 x 16 (output head / stem backward)
-    case 4: return small_map ? dispatch_conv<2, 2, 4, 2, 2>(k, a->taps, s) : dispatch_conv<2, 2, 8, 2, 2>(k, a->taps, s);
+    case 1: return small_map ? dispatch_conv<2, 2, 4, 4, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 4, 1>(k, a->taps, a->prologue, s);
+    case 2: return small_map ? dispatch_conv<2, 2, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 3, 2>(k, a->taps, a->prologue, s);
+    case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, a->prologue, s);  // 256 x 16 (output head / stem backward)
+    case 4: return small_map ? dispatch_conv<2, 2, 4, 2, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 2, 2>(k, a->taps, a->prologue, s);
     // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs
-    case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, s);
+    case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, a->prologue, s);
     default: ADM_FAIL(ADM_E_ARG, "adm_conv: unknown variant %d", variant);
   }
 }
