@@ -512,7 +512,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
 
-  // tiling variant (output-tile width): 5 = 192 (8 waves), 1 = 128, 2 = 96, 4 = 64, 3 = 16 (4 waves).
+  // tiling variant (output-tile width): 5 = 192, 6 = 128 (8 waves); 1 = 128, 2 = 96, 4 = 64, 3 = 16 (4 waves).
   // Measured on MI355X (tools/conv_bench.py): the 8-wave 192-wide tile shares one halo staging + prologue
   // transform among twice as many MFMAs and wins whenever it pads <= 10 %; otherwise the 96-wide tile is
   // the fastest per useful column unless it pads > 15 % (then 64-wide); on the 128-pixel tiles of 8x8
@@ -523,6 +523,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     const int w96 = ((a->cout + 95) / 96) * 96, w64 = ((a->cout + 63) / 64) * 64;
     if (a->cout <= 16) variant = 3;
     else if (w192 * 10 <= a->cout * 11) variant = 5;
+    else if (w128 * 10 <= a->cout * 11) variant = 6;
     else if (a->h * a->w <= 64) variant = (w128 <= w96) ? 1 : 2;
     else variant = (w96 * 0.85 <= w64) ? 2 : 4;
   }
@@ -535,6 +536,8 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     case 4: return small_map ? dispatch_conv<2, 2, 4, 2, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 2, 2>(k, a->taps, a->prologue, s);
     // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs
     case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, a->prologue, s);
+    // 8 waves, 128-wide tile (channel counts that are multiples of 128 but not of 192: the classifier)
+    case 6: return small_map ? dispatch_conv<2, 4, 4, 2, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2>(k, a->taps, a->prologue, s);
     default: ADM_FAIL(ADM_E_ARG, "adm_conv: unknown variant %d", variant);
   }
 }

@@ -19,7 +19,7 @@ BF16 = torch.bfloat16
 GN_EPS = 1e-5
 
 # bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
-# every conv launch appends (start_event, end_event, algorithmic_flops, (variant, taps, big_map)).
+# every conv launch appends (start_event, end_event, algorithmic_flops, (variant, taps, big_map, prologue)).
 CONV_PROFILE = None
 
 
@@ -31,6 +31,8 @@ def conv_variant(cout: int, hw: int) -> int:
         return 3
     if w192 * 10 <= cout * 11:
         return 5
+    if w128 * 10 <= cout * 11:
+        return 6
     if hw <= 64:
         return 1 if w128 <= w96 else 2
     return 2 if w96 * 0.85 <= w64 else 4
@@ -209,7 +211,7 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
         e0.record()
         check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
         e1.record()
-        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64)))
+        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64, a.prologue)))
         return out
     check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
     return out
