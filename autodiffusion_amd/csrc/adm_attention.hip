@@ -11,9 +11,9 @@
 //   a query column, so the row max/sum need two cross-lane shuffles (xor 16, 32) per tile
 //   O^T[d][query] += V^T . P^T       B = P^T taken straight from the S^T accumulators (the k-order
 //   of the contraction is permuted identically on the V^T side, so P never touches LDS);
-//   A = V^T staged transposed in LDS
+//   A = V^T read from the row-major LDS tile with the transposing load ds_read_b64_tr_b16
 // Block = 4 waves x 32 queries; K/V tiles of 64 keys shared through LDS.
-#include "adm_common.h"
+#include "adm_attn_common.h"
 
 namespace {
 
@@ -34,9 +34,10 @@ __global__ void __launch_bounds__(256)
 attn_kernel(const AttnK p) {
   constexpr int KS = D / 32;   // k-steps of QK^T
   constexpr int DT = D / 16;   // d tiles of the output
-  constexpr int KROW = D + PADE, VROW = KT + PADE;
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[KT * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[D * VROW];
+  constexpr int KROW = D + PADE;
+  // K and V tiles row-major, double-buffered: the next tile's global loads fly during this tile's MFMAs
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KT * KROW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
@@ -66,33 +67,24 @@ attn_kernel(const AttnK p) {
     for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
+  AdmTileRegs<KT, D, 256> kr, vr;
+  kr.load(base, p.C3, kcol, 0, p.T, tid);
+  vr.load(base, p.C3, vcol, 0, p.T, tid);
+  kr.store(Ks[0], KROW, tid);
+  vr.store(Vs[0], KROW, tid);
+  __syncthreads();
+
   const int ntiles = (p.T + KT - 1) / KT;
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int k0 = kt0 * KT;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (row-major) and V (transposed) tiles
-    constexpr int UNITS = KT * D / 8;
-#pragma unroll
-    for (int u0 = 0; u0 < UNITS; u0 += 256) {
-      const int u = u0 + tid;
-      if (u < UNITS) {
-        const int key = u / (D / 8), sg = u % (D / 8);
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (k0 + key < p.T) {
-          const uint16_t* row = base + (long long)(k0 + key) * p.C3;
-          kv = *reinterpret_cast<const uint4*>(row + kcol + sg * 8);
-          vv = *reinterpret_cast<const uint4*>(row + vcol + sg * 8);
-        }
-        *reinterpret_cast<uint4*>(&Ks[key * KROW + sg * 8]) = kv;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          Vt[(sg * 8 + 2 * e) * VROW + key] = (uint16_t)(w[e] & 0xffffu);
-          Vt[(sg * 8 + 2 * e + 1) * VROW + key] = (uint16_t)(w[e] >> 16);
-        }
-      }
+    const int cur = kt0 & 1;
+    const bool next = kt0 + 1 < ntiles;
+    if (next) {
+      kr.load(base, p.C3, kcol, k0 + KT, p.T, tid);
+      vr.load(base, p.C3, vcol, k0 + KT, p.T, tid);
     }
-    __syncthreads();
+    const uint16_t* Kc = Ks[cur];
+    const uint16_t* Vc = Vs[cur];
 
     // ---- S^T = K . Q^T  (4 key tiles x 2 query tiles)
     f32x4 st[4][2];
@@ -102,13 +94,14 @@ attn_kernel(const AttnK p) {
       for (int qt = 0; qt < 2; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kt][qt], 0, 0, 0);
       }
     }
     // ---- online softmax (per query column)
+    const bool ragged = k0 + KT > p.T;
     bf16x8 pf[2][2];  // [query tile][32-key block]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -117,16 +110,16 @@ attn_kernel(const AttnK p) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = k0 + kt * 16 + lq * 4 + r;
           float s = st[kt][qt][r];
-          if (key >= p.T) s = -1e30f;
+          if (ragged && k0 + kt * 16 + lq * 4 + r >= p.T) s = -1e30f;
           st[kt][qt][r] = s;
           mx = fmaxf(mx, s);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f((m_run[qt] - m_new) * p.scale_log2);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.scale_log2);
+      const float mneg = -m_new * p.scale_log2;
       m_run[qt] = m_new;
       float psum = 0.f;
       float pv[4][4];
@@ -134,13 +127,15 @@ attn_kernel(const AttnK p) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f((st[kt][qt][r] - m_new) * p.scale_log2);
+          const float e = __builtin_amdgcn_exp2f(st[kt][qt][r] * p.scale_log2 + mneg);
           pv[kt][r] = e;
           psum += e;
         }
       l_run[qt] = l_run[qt] * alpha + psum;
+      if (__any(alpha != 1.0f)) {  // wave-uniform: skip the O rescale once the running max has settled
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+        for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         bf16x8 f;
@@ -149,20 +144,23 @@ attn_kernel(const AttnK p) {
         pf[qt][kb] = f;
       }
     }
-    // ---- O^T += V^T . P^T ; contraction slot k = 8*lq + e  <->  key kb*32 + 16*(e>>2) + 4*lq + (e&3)
+    // ---- O^T += V^T . P^T ; contraction slot k = 8*lq + e  <->  key kb*32 + 16*(e>>2) + 4*lq + (e&3);
+    //      V^T fragments come from the row-major tile through the transposing LDS read
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const uint16_t* vr = &Vt[(dt * 16 + lc) * VROW + kb * 32 + lq * 4];
-        const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
-        const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        const bf16x8 vf = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kb], oacc[dt][qt], 0, 0, 0);
       }
     }
+    if (next) {
+      kr.store(Ks[cur ^ 1], KROW, tid);
+      vr.store(Vs[cur ^ 1], KROW, tid);
+    }
+    __syncthreads();
   }
 
   // ---- normalise and store: lane holds d = dt*16 + 4*lq .. +3 of query lc

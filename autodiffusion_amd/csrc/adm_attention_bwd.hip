@@ -11,7 +11,7 @@
 // dK/dV per 128-key block (loop over query tiles).  All MFMAs are v_mfma_f32_16x16x32_bf16; as in the
 // forward kernel the second product of each chain takes its B operand straight from the first
 // product's accumulators (k-order permuted identically on the LDS-transposed A side).
-#include "adm_common.h"
+#include "adm_attn_common.h"
 
 namespace {
 
@@ -54,46 +54,13 @@ delta_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout
   }
 }
 
-// stage a [TT x D] row tile (row-major, optional transposed copy) from a token-major tensor
-template <int D, bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void stage_tile(const uint16_t* base, long long row_stride, int col0, int r0, int rmax,
-                                           uint16_t* rowbuf, uint16_t* trbuf, int tid) {
-  constexpr int KROW = D + PADE, VROW = TT + PADE, UNITS = TT * D / 8;
-#pragma unroll
-  for (int u0 = 0; u0 < UNITS; u0 += 256) {
-    const int u = u0 + tid;
-    if (u < UNITS) {
-      const int r = u / (D / 8), sg = u % (D / 8);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (r0 + r < rmax) v = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * row_stride + col0 + sg * 8);
-      if (ROWMAJOR) *reinterpret_cast<uint4*>(&rowbuf[r * KROW + sg * 8]) = v;
-      if (TRANSPOSED) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          trbuf[(sg * 8 + 2 * e) * VROW + r] = (uint16_t)(w[e] & 0xffffu);
-          trbuf[(sg * 8 + 2 * e + 1) * VROW + r] = (uint16_t)(w[e] >> 16);
-        }
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* trbuf, int vrow, int row, int col) {
-  const uint16_t* vr = trbuf + row * vrow + col;
-  const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-  const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
-  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-}
-
 // ------------------------------------------------------------------------------------ dQ
 template <int D>
 __global__ void __launch_bounds__(256)
 attn_dq_kernel(const AttnBwdK p) {
-  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE, VROW = TT + PADE;
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[TT * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Vs[TT * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Kt[D * VROW];
+  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE;
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[2][TT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[2][TT * KROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
   const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
   const int qbase = blockIdx.x * BB + wave * BW;
@@ -127,13 +94,23 @@ attn_dq_kernel(const AttnBwdK p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  AdmTileRegs<TT, D, 256> kr, vr;
+  kr.load(base, p.C3, kcol, 0, p.T, tid);
+  vr.load(base, p.C3, vcol, 0, p.T, tid);
+  kr.store(Ks[0], KROW, tid);
+  vr.store(Vs[0], KROW, tid);
+  __syncthreads();
+
   const int ntiles = (p.T + TT - 1) / TT;
   for (int t0 = 0; t0 < ntiles; ++t0) {
-    const int k0 = t0 * TT;
-    __syncthreads();
-    stage_tile<D, true, true>(base, p.C3, kcol, k0, p.T, Ks, Kt, tid);
-    stage_tile<D, true, false>(base, p.C3, vcol, k0, p.T, Vs, nullptr, tid);
-    __syncthreads();
+    const int k0 = t0 * TT, cur = t0 & 1;
+    const bool next = t0 + 1 < ntiles;
+    if (next) {
+      kr.load(base, p.C3, kcol, k0 + TT, p.T, tid);
+      vr.load(base, p.C3, vcol, k0 + TT, p.T, tid);
+    }
+    const uint16_t* Kc = Ks[cur];
+    const uint16_t* Vc = Vs[cur];
     bf16x8 dsf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -145,8 +122,8 @@ attn_dq_kernel(const AttnBwdK p) {
         for (int qt = 0; qt < 2; ++qt) { st[kk][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vs[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
             st[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kk][qt], 0, 0, 0);
@@ -161,7 +138,7 @@ attn_dq_kernel(const AttnBwdK p) {
         for (int e = 0; e < 8; ++e) {
           const int kk = e >> 2, r = e & 3;
           const int key = k0 + (2 * kb + kk) * 16 + lq * 4 + r;
-          float pr = exp2f(st[kk][qt][r] * p.scale_log2 - lse[qt]);
+          float pr = __builtin_amdgcn_exp2f(st[kk][qt][r] * p.scale_log2 - lse[qt]);
           if (key >= p.T) pr = 0.f;
           f[e] = (__bf16)(pr * (dp[kk][qt][r] - dl[qt]));
         }
@@ -172,11 +149,16 @@ attn_dq_kernel(const AttnBwdK p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8 kt_f = tr_frag(Kt, VROW, dt * 16 + lc, kb * 32 + lq * 4);
+        const bf16x8 kt_f = adm_tr_frag(Kc, KROW, kb * 32, dt * 16, lc, lq);  // K^T from the row-major tile
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[qt][kb], acc[dt][qt], 0, 0, 0);
       }
+    if (next) {
+      kr.store(Ks[cur ^ 1], KROW, tid);
+      vr.store(Vs[cur ^ 1], KROW, tid);
+    }
+    __syncthreads();
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -198,18 +180,17 @@ attn_dq_kernel(const AttnBwdK p) {
 template <int D>
 __global__ void __launch_bounds__(256)
 attn_dkv_kernel(const AttnBwdK p) {
-  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE, VROW = TT + PADE;
-  __shared__ __attribute__((aligned(16))) uint16_t Qs[TT * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Gs[TT * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Qt[D * VROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Gt[D * VROW];
-  __shared__ float lse_s[TT], dl_s[TT];
+  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE;
+  __shared__ __attribute__((aligned(16))) uint16_t Qs[2][TT * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Gs[2][TT * KROW];
+  __shared__ float lse_s[2][TT], dl_s[2][TT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
   const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
   const int kbase = blockIdx.x * BB + wave * BW;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
   const uint16_t* dbase = p.dout + (long long)n * p.T * p.C;
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;
+  const long long sbase = ((long long)n * p.heads + hd) * p.T;
 
   // K^T / V^T B-operand fragments of this wave's 32 keys: lane (key lc, quarter lq) holds row[key][ks*32 + 8*lq ..]
   bf16x8 kf[2][KS], vf[2][KS];
@@ -233,19 +214,33 @@ attn_dkv_kernel(const AttnBwdK p) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) { dv[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int ntiles = (p.T + TT - 1) / TT;
-  for (int t0 = 0; t0 < ntiles; ++t0) {
-    const int q0 = t0 * TT;
-    __syncthreads();
-    stage_tile<D, true, true>(base, p.C3, qcol, q0, p.T, Qs, Qt, tid);
-    stage_tile<D, true, true>(dbase, p.C, hd * D, q0, p.T, Gs, Gt, tid);
+  AdmTileRegs<TT, D, 256> qr, gr;
+  float lse_r = 0.f, dl_r = 0.f;
+  auto load_rows = [&](int q0) {
+    qr.load(base, p.C3, qcol, q0, p.T, tid);
+    gr.load(dbase, p.C, hd * D, q0, p.T, tid);
     if (tid < TT) {
       const int q = q0 + tid;
-      const long long si = ((long long)n * p.heads + hd) * p.T + (q < p.T ? q : 0);
-      lse_s[tid] = q < p.T ? p.lse[si] : 0.f;
-      dl_s[tid] = q < p.T ? p.delta[si] : 0.f;
+      lse_r = q < p.T ? p.lse[sbase + q] : 0.f;
+      dl_r = q < p.T ? p.delta[sbase + q] : 0.f;
     }
-    __syncthreads();
+  };
+  auto store_rows = [&](int buf) {
+    qr.store(Qs[buf], KROW, tid);
+    gr.store(Gs[buf], KROW, tid);
+    if (tid < TT) { lse_s[buf][tid] = lse_r; dl_s[buf][tid] = dl_r; }
+  };
+  load_rows(0);
+  store_rows(0);
+  __syncthreads();
+
+  const int ntiles = (p.T + TT - 1) / TT;
+  for (int t0 = 0; t0 < ntiles; ++t0) {
+    const int q0 = t0 * TT, cur = t0 & 1;
+    const bool next = t0 + 1 < ntiles;
+    if (next) load_rows(q0 + TT);
+    const uint16_t* Qc = Qs[cur];
+    const uint16_t* Gc = Gs[cur];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {     // 32-query block of the tile
       bf16x8 pf[2], dsf[2];             // per key tile
@@ -259,8 +254,8 @@ attn_dkv_kernel(const AttnBwdK p) {
           dp[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qs[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-            const bf16x8 ga = *reinterpret_cast<const bf16x8*>(&Gs[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+            const bf16x8 ga = *reinterpret_cast<const bf16x8*>(&Gc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
             st[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], st[qq], 0, 0, 0);
             dp[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[kt][ks], dp[qq], 0, 0, 0);
           }
@@ -270,18 +265,18 @@ attn_dkv_kernel(const AttnBwdK p) {
         for (int e = 0; e < 8; ++e) {
           const int qq = e >> 2, r = e & 3;
           const int ql = (2 * qb + qq) * 16 + lq * 4 + r;  // query row within the tile
-          float pr = exp2f(st[qq][r] * p.scale_log2 - lse_s[ql]);
+          float pr = __builtin_amdgcn_exp2f(st[qq][r] * p.scale_log2 - lse_s[cur][ql]);
           if (q0 + ql >= p.T) pr = 0.f;
           f[e] = (__bf16)pr;
-          g[e] = (__bf16)(pr * (dp[qq][r] - dl_s[ql]));
+          g[e] = (__bf16)(pr * (dp[qq][r] - dl_s[cur][ql]));
         }
         pf[kt] = f;
         dsf[kt] = g;
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const bf16x8 gt_f = tr_frag(Gt, VROW, dt * 16 + lc, qb * 32 + lq * 4);
-        const bf16x8 qt_f = tr_frag(Qt, VROW, dt * 16 + lc, qb * 32 + lq * 4);
+        const bf16x8 gt_f = adm_tr_frag(Gc, KROW, qb * 32, dt * 16, lc, lq);  // dA^T
+        const bf16x8 qt_f = adm_tr_frag(Qc, KROW, qb * 32, dt * 16, lc, lq);  // Q^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt_f, pf[kt], dv[dt][kt], 0, 0, 0);
@@ -289,6 +284,8 @@ attn_dkv_kernel(const AttnBwdK p) {
         }
       }
     }
+    if (next) store_rows(cur ^ 1);
+    __syncthreads();
   }
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {

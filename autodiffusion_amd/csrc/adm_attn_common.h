@@ -1,0 +1,46 @@
+// Shared pieces of the attention forward / backward kernels (gfx950).
+#pragma once
+#include "adm_common.h"
+
+typedef __attribute__((ext_vector_type(4))) short adm_s16x4;
+
+// MFMA A-operand fragment (16 rows x 32 k, bf16) of the TRANSPOSE of a row-major LDS tile, read with the
+// hardware transposing load ds_read_b64_tr_b16: lane (lc = l & 15, lq = l >> 4) receives
+//   element e (0..7) = tile[row0 + 16*(e>>2) + 4*lq + (e&3)][col0 + lc]
+// i.e. "column col0+lc" for a k-order that matches a B operand taken straight from 16x16x32
+// accumulators (4 consecutive rows per lane quarter, two 16-row tiles per 32-deep k-step).
+// Each 16-lane group reads a 4-row x 16-column block; lane 4q+p supplies the address of row q, columns 4p..4p+3.
+__device__ __forceinline__ bf16x8 adm_tr_frag(const uint16_t* tile, int row_stride, int row0, int col0, int lc, int lq) {
+  const uint16_t* p0 = tile + (row0 + 4 * lq + (lc >> 2)) * row_stride + col0 + 4 * (lc & 3);
+  const adm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) adm_s16x4*)p0);
+  const adm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) adm_s16x4*)(p0 + 16 * row_stride));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// [ROWS x D] bf16 tile of a token-major tensor, register-staged: issue the loads early, write late.
+template <int ROWS, int D, int NT>
+struct AdmTileRegs {
+  static constexpr int UNITS = ROWS * D / 8;
+  static constexpr int PER = (UNITS + NT - 1) / NT;
+  uint4 v[PER];
+  __device__ __forceinline__ void load(const uint16_t* base, long long row_stride, int col0, int r0, int rmax, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * NT;
+      const int r = u / (D / 8), sg = u % (D / 8);
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (u < UNITS && r0 + r < rmax) x = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * row_stride + col0 + sg * 8);
+      v[i] = x;
+    }
+  }
+  __device__ __forceinline__ void store(uint16_t* tile, int krow, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * NT;
+      if (u < UNITS) *reinterpret_cast<uint4*>(&tile[(u / (D / 8)) * krow + (u % (D / 8)) * 8]) = v[i];
+    }
+  }
+};
