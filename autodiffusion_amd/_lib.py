@@ -51,6 +51,7 @@ SIGNATURES = {
     "adm_timestep_embedding": (_I, [_P, _P, _I, _I, _F, _P]),
     "adm_linear_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "adm_stem_conv3x3": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_nchw_to_nhwc_pad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_gn_partial": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "adm_gn_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "adm_resample": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -116,6 +116,15 @@ def stem_conv3x3(x_nchw, w, b):
     return out
 
 
+def nchw_to_nhwc_pad(x_nchw, cpad: int = 32):
+    """fp32 NCHW image -> bf16 NHWC with channels zero-padded to cpad (input of the MFMA stem conv)."""
+    n, c, h, w = x_nchw.shape
+    out = torch.empty((n, h, w, cpad), dtype=BF16, device=x_nchw.device)
+    check(_lib.load().adm_nchw_to_nhwc_pad(_ptr(x_nchw, torch.float32, "x"), _ptr(out), n, c, h, w, cpad, _stream()),
+          "adm_nchw_to_nhwc_pad")
+    return out
+
+
 def gn_slabs(hw: int) -> int:
     return max(1, min(64, hw // 64))
 

@@ -186,7 +186,11 @@ class AdmNet(HipModule):
         for b in self.plan.all_blocks():
             p = b.prefix
             if isinstance(b, StemSpec):
-                pr.blocks[p] = dict(w=f32(f"{p}.weight"), b=f32(f"{p}.bias"))
+                # stem on the MFMA conv kernel: input channels zero-padded to one 32-channel chunk
+                w = P[f"{p}.weight"].to(torch.float32)
+                wpad = torch.zeros((b.cout, 32, 3, 3), dtype=torch.float32, device=dev)
+                wpad[:, :b.cin] = w
+                pr.blocks[p] = dict(w=ops.pack_conv_weight(wpad), b=f32(f"{p}.bias"))
             elif isinstance(b, ResBlockSpec):
                 ws.append(f32(f"{p}.emb_layers.1.weight"))
                 bs.append(f32(f"{p}.emb_layers.1.bias"))
@@ -298,7 +302,7 @@ class AdmNet(HipModule):
         for blk in seq:
             if isinstance(blk, StemSpec):
                 d = pr.blocks[blk.prefix]
-                h = ops.stem_conv3x3(x_nchw, d["w"], d["b"])
+                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32), d["w"], d["b"], blk.cout, 9)
                 if tape is not None:
                     tape.append(("stem", blk, {}))
             elif isinstance(blk, ResBlockSpec):

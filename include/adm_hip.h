@@ -94,6 +94,13 @@ int adm_linear_f32(const float* in, const float* w, const float* bias, const flo
 int adm_stem_conv3x3(const float* x_nchw, const float* w /*[Cout,Cin,3,3]*/, const float* bias,
                      adm_bf16* out_nhwc, int n, int cin, int h, int w_, int cout, void* stream);
 
+/* The same layer on the MFMA path (what the engine uses): cast the image to bf16 NHWC with the channels
+ * zero-padded to cpad = 32, then run adm_conv (3x3, raw prologue) with the stem weight zero-padded to 32
+ * input channels.  The image is rounded to bf16 like every other activation (the reference rounds it to
+ * fp16, unet.py:656).                                                                              */
+int adm_nchw_to_nhwc_pad(const float* x_nchw, adm_bf16* out_nhwc, int n, int c, int h, int w, int cpad,
+                         void* stream);
+
 /* ---------------------------------------------------------------- GroupNorm (K2/K3 statistics)
  * GroupNorm32(32, C) statistics over a (virtually concatenated) bf16 NHWC tensor, in fp32 /
  * fp64 (nn.py:17-19).  Two launches:
