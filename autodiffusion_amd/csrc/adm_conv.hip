@@ -224,9 +224,9 @@ conv_kernel(const ConvK p) {
     }
   };
 
-  // ---- prologue: chunk 0 halo (and the affine table of chunk 1 for the 1x1 pipeline)
+  // ---- prologue: chunk 0 halo; the affine tables of chunks 0 and 1 (they are staged two chunks ahead)
   stage_affine(0, 0);
-  if (TAPS == 1 && chunks > 1) stage_affine(1, 1);
+  if (chunks > 1) stage_affine(1, 1);
   {
     uint4 h0[PASSES];
 #pragma unroll
@@ -247,24 +247,36 @@ conv_kernel(const ConvK p) {
       const int hb = c & 1;
       const int step0 = c * 9;
       uint4 hprev = make_uint4(0, 0, 0, 0);
+      float4 affv = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         // next chunk's halo: pass t is fetched now; pass t-1 (fetched during the previous tap) is
         // transformed and parked in the other halo buffer
         uint4 hcur = make_uint4(0, 0, 0, 0);
         if constexpr (MORE) {
-          if (t == 0) stage_affine(c + 1, hb ^ 1);
           if (t < PASSES) hcur = halo_load(c + 1, t);
         }
         if (MORE || t + 2 < 9) load_w(step0 + t + 2, wreg[(t + 2) % 3]);
-        if (t == 1) __syncthreads();  // abuf[hb^1] (written at tap 0) visible to every wave
+        // small maps (128-pixel tiles): a mid-chunk rendezvous keeps the waves that share weight fragments
+        // in step (L1 reuse); on the 256-pixel tiles it only cost time and is omitted
+        if (HALO <= 200 && t == 1) __syncthreads();
+        if constexpr (MORE && PRO != 0) {
+          // affine table of chunk c+2 -> abuf[hb] (its readers, chunk c-1's transforms, are behind the last
+          // barrier): fetched at tap 0, parked at tap 7 so that no wave ever waits on that load
+          if (t == 0 && c + 2 < chunks && tid < p.TI * 16) {
+            const int n = min(img0 + (tid >> 4), p.N - 1);
+            affv = *reinterpret_cast<const float4*>(((tid & 15) < 8 ? p.aa : p.ab) + (long long)n * Cin + (c + 2) * KC + (tid & 7) * 4);
+          }
+          if (t == 7 && c + 2 < chunks && tid < p.TI * 16)
+            *reinterpret_cast<float4*>(abuf + (hb * TI_MAX + (tid >> 4)) * 64 + ((tid & 15) < 8 ? 0 : 32) + (tid & 7) * 4) = affv;
+        }
         if constexpr (MORE) {
           if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
         }
         hprev = hcur;
         mfma_tap(halo + hb * (HSLOT * ROWB) + ((t / 3) * HW2 + (t % 3)) * ROWB, wreg[t % 3]);
       }
-      __syncthreads();  // halo[hb^1] complete; every wave is done reading halo[hb]
+      __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
     };
     for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
     chunk(chunks - 1, std::false_type{});
@@ -380,6 +392,272 @@ conv_kernel(const ConvK p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The dominant layer class (3x3, maps >= 16x16, Cout a multiple of 192) on v_mfma_f32_32x32x16_bf16:
+// the same pipeline as conv_kernel<2,4,8,3,...,9,324,PRO>, but a 32x32x16 MFMA occupies the SIMD's issue
+// port for 8 of its 32 cycles (16x16x32: 8 of 16), which leaves the partner wave twice the issue slots
+// for the prologue VALU work, the LDS reads and the loads.  8 waves as 4 (pixels) x 2 (channels); each
+// wave owns 64 pixels x 96 channels = 2 x 3 tiles of 32x32 (96 accumulator registers).
+// Weights come from the 32x32 fragment-ordered image [Cin/32][9][ceil(Cout/32)][2 k-steps][64][8].
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int PRO>
+__global__ void __launch_bounds__(512, 2)
+conv32_kernel(const ConvK p) {
+  constexpr int NT = 512, WN = 2, TM = 2, TN = 3, BN = 192, HALO = 324, WMR = 4;
+  constexpr int PASSES = (HALO * 4 + NT - 1) / NT;  // 3
+  constexpr int HSLOT = halo_slots<NT, HALO>();      // 384
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const halo = smem;
+  float* const abuf = reinterpret_cast<float*>(smem + 2 * HSLOT * ROWB);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lp = lane & 31, lh = lane >> 5;
+
+  const int nb = blockIdx.x % p.nblocks_n;
+  const int mt = blockIdx.x / p.nblocks_n;
+  const int HW2 = p.TW + 2;
+  const int HPI = (p.TH + 2) * HW2;
+  const int Cin = p.C0 + p.C1;
+  const int HWimg = p.H * p.W;
+  const int per_img = p.tiles_x * p.tiles_y;
+  const int img0 = mt / per_img;
+  const int y0 = ((mt % per_img) / p.tiles_x) * p.TH, x0 = ((mt % per_img) % p.tiles_x) * p.TW;
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in0 + (long long)img0 * HWimg * p.C0), 0, HWimg * p.C0 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.C1 ? p.in1 + (long long)img0 * HWimg * p.C1 : p.in0), 0, p.C1 ? HWimg * p.C1 * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+
+  int pixrel[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int hp = (tid + ps * NT) >> 2;
+    int off = -1;
+    if (hp < HPI) {
+      const int y = y0 + hp / HW2 - 1, x = x0 + hp % HW2 - 1;
+      if (y >= 0 && y < p.H && x >= 0 && x < p.W) off = y * p.W + x;
+    }
+    pixrel[ps] = off;
+  }
+  const int seg = tid & 3;
+  const int hslot = (tid >> 2) * ROWB + seg * 16;
+
+  // activation (B operand) fragment of a 32-pixel tile: lane (pixel lp, half lh) reads 16 bytes = k 8*lh..8*lh+7
+  const int alane = ((lp / p.TW) * HW2 + lp % p.TW) * ROWB + lh * 16;
+  int aoff[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) aoff[i] = (((wm * TM + i) * 32) / p.TW) * HW2 * ROWB;
+  // weight (A operand) fragments: tile32 x k-step
+  const int ntiles32 = (p.Cout + 31) / 32;
+  unsigned wofs[TN][2];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int tile = nb * (BN / 32) + wn * TN + j;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wofs[j][ks] = tile < ntiles32 ? (unsigned)(((tile * 2 + ks) * 64 + lane) * 16) : OOB;
+  }
+  const unsigned wstep = (unsigned)ntiles32 * 2048u;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int chunks = Cin / KC;
+  const int c0chunks = p.C0 / KC;
+
+  auto halo_load = [&](int c, int ps) -> uint4 {
+    const bool first = c < c0chunks;
+    const int cs = first ? p.C0 : p.C1, co = (first ? c : c - c0chunks) * KC;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
+    return bufload16(rs, voff, 0);
+  };
+  auto stage_affine = [&](int c, int buf) {
+    if constexpr (PRO != 0) {
+      if (tid < 16) {
+        const int part = tid & 15;
+        const float* s = (part < 8 ? p.aa : p.ab) + (long long)img0 * Cin + c * KC + (part & 7) * 4;
+        *reinterpret_cast<float4*>(abuf + buf * 64 + (part < 8 ? 0 : 32) + (part & 7) * 4) = *reinterpret_cast<const float4*>(s);
+      }
+    }
+  };
+  auto halo_write = [&](uint4 v, int ps, int buf) {
+    if constexpr (PRO != 0) {
+      const float* ab = abuf + buf * 64 + seg * 8;
+      float a8[8], b8[8];
+      *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ab);
+      *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ab + 4);
+      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 32);
+      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 36);
+      uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      const bool valid = pixrel[ps] >= 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+        lo = a8[2 * j] * lo + b8[2 * j];
+        hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
+        if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
+        const uint32_t pk = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        u[j] = valid ? pk : 0u;
+      }
+      v = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+    *reinterpret_cast<uint4*>(halo + buf * (HSLOT * ROWB) + ps * (NT / 4) * ROWB + hslot) = v;
+  };
+  auto load_w = [&](int step, uint4 (&dst)[TN][2]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) dst[j][ks] = bufload16(rsw, wofs[j][ks], (unsigned)step * wstep);
+  };
+  auto mfma_tap = [&](const unsigned char* hp, const uint4 (&w)[TN][2]) {
+    const unsigned char* hl = hp + alane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i] + ks * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[j][ks]), af, acc[i][j], 0, 0, 0);
+      }
+  };
+
+  stage_affine(0, 0);
+  {
+    uint4 h0[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) h0[ps] = halo_load(0, ps);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) halo_write(h0[ps], ps, 0);
+  }
+  uint4 wreg[3][TN][2];
+  load_w(0, wreg[0]);
+  load_w(1, wreg[1]);
+  __syncthreads();
+  auto chunk = [&](int c, auto more_) {
+    constexpr bool MORE = decltype(more_)::value;
+    const int hb = c & 1;
+    const int step0 = c * 9;
+    uint4 hprev = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      uint4 hcur = make_uint4(0, 0, 0, 0);
+      if constexpr (MORE) {
+        if (t == 0) stage_affine(c + 1, hb ^ 1);
+        if (t < PASSES) hcur = halo_load(c + 1, t);
+      }
+      if (MORE || t + 2 < 9) load_w(step0 + t + 2, wreg[(t + 2) % 3]);
+      if (t == 1) __syncthreads();
+      if constexpr (MORE) {
+        if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
+      }
+      hprev = hcur;
+      mfma_tap(halo + hb * (HSLOT * ROWB) + ((t / 3) * HW2 + (t % 3)) * ROWB, wreg[t % 3]);
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
+  chunk(chunks - 1, std::false_type{});
+
+  // ---- epilogue (bf16 NHWC): stage one wave-row (64 pixels x 192 channels) at a time, coalesced rows out.
+  // 32x32 accumulator: register e -> channel (e&3) + 8*(e>>2) + 4*lh of the tile, pixel lp.
+  constexpr int RPX = TM * 32, EROW = BN * 2 + 16, SEGS = BN / 8;
+  uint16_t* const outp = reinterpret_cast<uint16_t*>(p.out);
+  for (int r = 0; r < WMR; ++r) {
+    __syncthreads();
+    if (wm == r) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch0 = (wn * TN + j) * 32 + 8 * g + 4 * lh;
+          const int gch = nb * BN + ch0;
+          float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gch + 3 < p.Cout) bs = *reinterpret_cast<const float4*>(p.bias + gch);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            uint2 o;
+            o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 0] + bs.x) | ((uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 1] + bs.y) << 16);
+            o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 2] + bs.z) | ((uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 3] + bs.w) << 16);
+            *reinterpret_cast<uint2*>(smem + (i * 32 + lp) * EROW + ch0 * 2) = o;
+          }
+        }
+    }
+    __syncthreads();
+    for (int u = tid; u < RPX * SEGS; u += NT) {
+      const int pl = u / SEGS, sg = u % SEGS;
+      const int gch = nb * BN + sg * 8;
+      if (gch >= p.Cout) continue;
+      const int m = r * RPX + pl;
+      const long long pix = ((long long)img0 * p.H + y0 + m / p.TW) * p.W + x0 + m % p.TW;
+      uint4 v = *reinterpret_cast<const uint4*>(smem + pl * EROW + sg * 16);
+      if (p.res) {
+        const uint4 rr = *reinterpret_cast<const uint4*>(p.res + pix * p.Cout + gch);
+        uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
+          const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
+          a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        }
+        v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+      }
+      *reinterpret_cast<uint4*>(outp + pix * p.Cout + gch) = v;
+    }
+  }
+}
+
+// fp32 [cout][cin][taps] -> bf16 [cin/32][taps][ceil(cout/32)][2][lane = h*32 + r][8]
+//   channel = tile*32 + r, k = chunk*32 + ks*16 + h*8 + e  (A-operand fragment of v_mfma_f32_32x32x16_bf16)
+__global__ void __launch_bounds__(256)
+pack_weight32_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin, int taps, int ntiles32) {
+  const long long total = (long long)(cin / KC) * taps * ntiles32 * 1024;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), ln = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
+    long long r = i >> 10;
+    const int tile = (int)(r % ntiles32); r /= ntiles32;
+    const int tap = (int)(r % taps);
+    const int chunk = (int)(r / taps);
+    const int ch = tile * 32 + (ln & 31);
+    const int k = chunk * KC + ks * 16 + (ln >> 5) * 8 + e;
+    float v = 0.0f;
+    if (ch < cout) v = w[((long long)ch * cin + k) * taps + tap];
+    out[i] = adm_f32_to_bf16(v);
+  }
+}
+
+template <int PRO>
+int launch_conv32(const ConvK& k, int m_tiles, hipStream_t s) {
+  constexpr int smem = conv_smem_bytes<512, 192, 324, 64>();
+  ConvK kk = k;
+  kk.nblocks_n = (k.Cout + 191) / 192;
+  const long long blocks = (long long)m_tiles * kk.nblocks_n;
+  ADM_REQUIRE(blocks < (1ll << 31), ADM_E_SHAPE, "adm_conv: grid too large");
+  static bool attr_set_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_set_dev[dev & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32_kernel<PRO>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set_dev[dev & 63] = true;
+  }
+  hipLaunchKernelGGL((conv32_kernel<PRO>), dim3((unsigned)blocks), dim3(512), smem, s, kk);
+  return adm_check_launch("adm_conv");
+}
+
 // fp32 [cout][cin][taps] -> bf16 [cin/32][taps][ceil(cout/16)][lane = q*16 + r][8]
 //   channel = tile*16 + r, k = chunk*32 + q*8 + e  (A-operand fragment of v_mfma_f32_16x16x32_bf16)
 __global__ void __launch_bounds__(256)
@@ -485,6 +763,23 @@ extern "C" int adm_pack_conv_weight(const float* w, adm_bf16* out, int cout, int
   return adm_check_launch("adm_pack_conv_weight");
 }
 
+extern "C" int64_t adm_packed_weight32_elems(int cout, int cin, int taps) {
+  if (cout <= 0 || cin <= 0 || cin % KC != 0 || (taps != 1 && taps != 9)) return -1;
+  return (int64_t)(cin / KC) * taps * ((cout + 31) / 32) * 1024;
+}
+
+extern "C" int adm_pack_conv_weight32(const float* w, adm_bf16* out, int cout, int cin, int taps, void* stream) {
+  ADM_REQUIRE(w && out, ADM_E_ARG, "adm_pack_conv_weight32: null pointer");
+  ADM_REQUIRE(cout > 0 && cin > 0 && cin % KC == 0 && (taps == 1 || taps == 9), ADM_E_SHAPE,
+              "adm_pack_conv_weight32: cout=%d cin=%d taps=%d unsupported", cout, cin, taps);
+  const int nt32 = (cout + 31) / 32;
+  const long long total = (long long)(cin / KC) * taps * nt32 * 1024;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, cout, cin, taps, nt32);
+  return adm_check_launch("adm_pack_conv_weight32");
+}
+
 extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE(a, ADM_E_ARG, "adm_conv: null args");
   ADM_REQUIRE(a->in0 && a->w_packed && a->bias && a->out, ADM_E_ARG, "adm_conv: null pointer");
@@ -526,6 +821,18 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     else if (w128 * 10 <= a->cout * 11) variant = 6;
     else if (a->h * a->w <= 64) variant = (w128 <= w96) ? 1 : 2;
     else variant = (w96 * 0.85 <= w64) ? 2 : 4;
+  }
+  if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
+    ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out");
+    ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1, ADM_E_SHAPE, "adm_conv: variant 7 needs maps >= 16x16");
+    k.w = a->w_packed32;
+    k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * 9 * ((a->cout + 31) / 32) * 2048);
+    const int m_tiles = k.N * k.tiles_x * k.tiles_y;
+    switch (a->prologue) {
+      case 0: return launch_conv32<0>(k, m_tiles, s);
+      case 1: return launch_conv32<1>(k, m_tiles, s);
+      default: return launch_conv32<2>(k, m_tiles, s);
+    }
   }
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
   const bool small_map = a->h * a->w <= 64;

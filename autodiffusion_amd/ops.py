@@ -189,8 +189,24 @@ def pack_conv_weight(w):
     return out
 
 
+def pack_conv_weight32(w):
+    """Same weight in the 32x32x16 fragment order (enables adm_conv's variant 7)."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = 1
+    for s in w.shape[2:]:
+        taps *= s
+    lib = _lib.load()
+    elems = lib.adm_packed_weight32_elems(cout, cin, taps)
+    if elems < 0:
+        raise AdmError(f"pack_conv_weight32: unsupported weight shape {tuple(w.shape)}")
+    w32 = w.detach().to(torch.float32).contiguous()
+    out = torch.empty((elems,), dtype=BF16, device=w.device)
+    check(lib.adm_pack_conv_weight32(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight32")
+    return out
+
+
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
-         out_f32_nchw=False, variant=0, out=None):
+         out_f32_nchw=False, variant=0, out=None, w_packed32=None):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): bf16 NHWC.  Returns bf16 NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].
@@ -214,6 +230,9 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, c1, cout
     if variant == 0:
         variant = conv_variant(cout, h * w)
+        if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw:
+            variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
+    a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

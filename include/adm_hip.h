@@ -142,13 +142,19 @@ typedef struct adm_conv_args {
   int32_t taps;      /* 9 or 1 */
   int32_t prologue;  /* 0,1,2  */
   int32_t out_mode;  /* 0,1    */
-  int32_t variant;   /* tiling variant, 0 = auto (see adm_conv_variants) */
+  int32_t variant;   /* tiling variant, 0 = auto */
+  const adm_bf16* w_packed32; /* optional: the same weight in the 32x32x16 fragment order
+                                 (adm_pack_conv_weight32); enables variant 7, the v_mfma_f32_32x32x16_bf16
+                                 kernel for 3x3 convs on maps >= 16x16 */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 
 /* fp32 [cout, cin, kh, kw] (kh*kw = taps) -> bf16 fragment-ordered image
  * [cin/32][taps][ceil(cout/16)][64 lanes][8]; out must hold adm_packed_weight_elems().   */
 int64_t adm_packed_weight_elems(int cout, int cin, int taps);
+/* 32x32x16 fragment order [cin/32][taps][ceil(cout/32)][2][64 lanes][8]. */
+int64_t adm_packed_weight32_elems(int cout, int cin, int taps);
+int adm_pack_conv_weight32(const float* w, adm_bf16* out, int cout, int cin, int taps, void* stream);
 int adm_pack_conv_weight(const float* w, adm_bf16* out, int cout, int cin, int taps, void* stream);
 
 /* ---------------------------------------------------------------- attention (K5)

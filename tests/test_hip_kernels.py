@@ -177,6 +177,11 @@ CONV_CASES = [
     (1, 16, 64, 0, 256, 9, 2, False, False, 2),
     (1, 16, 64, 0, 256, 9, 2, False, False, 4),
     (2, 32, 96, 0, 16, 9, 2, False, False, 3),
+    (2, 16, 64, 0, 192, 9, 2, True, False, 5),
+    (2, 16, 64, 0, 128, 9, 2, True, False, 6),
+    (2, 16, 64, 0, 192, 9, 2, True, False, 7),    # 32x32x16 MFMA kernel
+    (1, 32, 64, 32, 384, 9, 0, False, False, 7),  # ... raw prologue, virtual concat, two channel blocks
+    (3, 64, 32, 0, 96, 9, 1, True, False, 7),     # ... Cout below one tile: padded columns
 ]
 
 
@@ -199,7 +204,8 @@ def test_conv_fused(ops, case):
     if use_res:
         ref = ref + res
     wp = ops.pack_conv_weight(w.to(DEV))
-    got = ops.conv(nhwc_dev(x[:, :c0]), wp, b.to(DEV), cout, taps,
+    wp32 = ops.pack_conv_weight32(w.to(DEV)) if variant == 7 else None
+    got = ops.conv(nhwc_dev(x[:, :c0]), wp, b.to(DEV), cout, taps, w_packed32=wp32,
                    x1=nhwc_dev(x[:, c0:]) if c1 else None,
                    aff=(a_.to(DEV), b_.to(DEV)) if prologue else None, silu=(prologue == 2),
                    res=nhwc_dev(res) if use_res else None, out_f32_nchw=f32, variant=variant)

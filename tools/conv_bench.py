@@ -44,24 +44,27 @@ def main():
         x1 = (torch.randn(n, hw, hw, c1, device=DEV)).to(torch.bfloat16) if c1 else None
         w = torch.randn(cout, cin, k, k, device=DEV) * (cin * taps) ** -0.5
         wp = ops.pack_conv_weight(w)
+        wp32 = ops.pack_conv_weight32(w) if (taps == 9 and hw >= 16) else None
+        if variant == 7 and wp32 is None:
+            continue
         b = torch.randn(cout, device=DEV) * 0.1
         aff = (1 + 0.1 * torch.randn(n, cin, device=DEV), 0.1 * torch.randn(n, cin, device=DEV)) if prologue else None
         r = torch.randn(n, hw, hw, cout, device=DEV).to(torch.bfloat16) if res else None
         out = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
         for _ in range(2):
-            ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out)
+            ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out, w_packed32=wp32)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
-            ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out)
+            ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out, w_packed32=wp32)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         fl = 2.0 * n * hw * hw * cout * cin * taps
         tot_f += fl
         tot_t += ms
-        print(f"{name:36s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s  (variant {ops.conv_variant(cout, hw * hw) if variant == 0 else variant})")
+        print(f"{name:36s} {ms * 1e3:9.1f} us  {fl / ms / 1e9:8.1f} TFLOP/s  (variant {variant})")
     print(f"{'TOTAL':36s} {tot_t * 1e3:9.1f} us  {tot_f / tot_t / 1e9:8.1f} TFLOP/s")
 
 
