@@ -30,13 +30,20 @@ from .evaluate import CandidateEvaluator
 from .fid import ActivationAccumulator, FIDStatistics, cal_fid
 from .schedule import space_timesteps
 
+def _local_stats(acc):
+    n, s1, s2 = acc.n, acc.s1.cpu().numpy(), acc.s2.cpu().numpy()
+    mu = s1 / n
+    return mu, (s2 - n * np.outer(mu, mu)) / (n - 1)
+
+
 choice = lambda x: x[np.random.randint(len(x))] if isinstance(x, tuple) else choice(tuple(x))  # noqa: E731
 
 
 class EvolutionSearcher(object):
 
     def __init__(self, args, model, base_diffusion, time_step, classifier=None, search_space=None,
-                 evaluator=None, ref_stats=None, features=None, feature_dim=2048, variant=None):
+                 evaluator=None, ref_stats=None, features=None, feature_dim=2048, variant=None,
+                 population_parallel=False):
         self.args = args
         self.model = model
         self.base_diffusion = base_diffusion
@@ -71,6 +78,13 @@ class EvolutionSearcher(object):
             # (mu, sigma) written from it -- unpickling foreign files is not done here
             z = np.load(args.ref_path, allow_pickle=False)
             self.ref_stats = FIDStatistics(z["mu"], z["sigma"])
+        # population parallelism: within an epoch candidate GENERATION never looks at
+        # FID values (legality is only the visited-set dedupe; parents are the top-k frozen at epoch start),
+        # so candidates are generated first -- with the reference's exact random / np.random draw order, on
+        # every rank identically -- queued, then evaluated rank r -> candidates r, r+W, ... (whole-candidate
+        # FID local to one GPU) and the FIDs are all-gathered back in order.
+        self.population_parallel = population_parallel
+        self._pending = []
         self._ev = None
         if model is not None:
             self._ev = CandidateEvaluator(
@@ -84,6 +98,22 @@ class EvolutionSearcher(object):
         self._ev.set_candidate(list(use_timesteps))
 
     def get_cand_fid(self, cand=None, args=None):
+        if self.population_parallel:
+            return self._cand_fid_local(cand, args)
+        return self._cand_fid_sharded(cand, args)
+
+    def _cand_fid_local(self, cand, args):
+        """Whole candidate on this rank alone (population-parallel mode): no collective inside."""
+        import torch.distributed as dist
+        was = dist.is_available() and dist.is_initialized()
+        saved = (dist_util.get_world_size, dist_util.get_rank)
+        dist_util.get_world_size, dist_util.get_rank = (lambda: 1), (lambda: 0)
+        try:
+            return self._cand_fid_sharded(cand, args, allow_barrier=not was)
+        finally:
+            dist_util.get_world_size, dist_util.get_rank = saved
+
+    def _cand_fid_sharded(self, cand=None, args=None, allow_barrier=True):
         args = args if args is not None else self.args
         t1 = time.time()
         self._ev.set_candidate(cand)
@@ -109,14 +139,19 @@ class EvolutionSearcher(object):
             produced += args.batch_size * world
             batch_idx += 1
             logger.log('created ' + str(min(produced, batch_idx * args.batch_size * world)) + ' samples')
-        if world > 1:
+        if world > 1 and allow_barrier:
             import torch.distributed as dist
             dist.barrier()
         logger.log("sampling complete")
         sample_time = time.time() - t1
         t1 = time.time()
         if acc is not None:
-            fid = float(acc.statistics().frechet_distance(self.ref_stats))
+            grp = None
+            if world == 1 and self.population_parallel:
+                st = FIDStatistics(*_local_stats(acc))
+            else:
+                st = acc.statistics(grp)
+            fid = float(st.frechet_distance(self.ref_stats))
         else:
             if world > 1:
                 raise NotImplementedError("host-evaluator FID with several ranks: pass a device `features` function "
@@ -151,10 +186,36 @@ class EvolutionSearcher(object):
         if 'visited' in info:
             logger.log('cand: {} has visited!'.format(cand))
             return False
-        info['fid'] = self.get_cand_fid(args=self.args, cand=eval(cand))
-        logger.log('cand: {}, fid: {}'.format(cand, info['fid']))
+        if self.population_parallel:
+            self._pending.append(cand)  # evaluated by flush_pending(), sharded over ranks
+        else:
+            info['fid'] = self.get_cand_fid(args=self.args, cand=eval(cand))
+            logger.log('cand: {}, fid: {}'.format(cand, info['fid']))
         info['visited'] = True
         return True
+
+    def flush_pending(self):
+        """Evaluate every queued candidate: rank r takes candidates r, r+W, ...; one all_gather of the FIDs."""
+        if not self._pending:
+            return
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        world = dist.get_world_size() if multi else 1
+        rank = dist.get_rank() if multi else 0
+        pending, self._pending = self._pending, []
+        fids = np.full(len(pending), np.nan, dtype=np.float64)
+        for i in range(rank, len(pending), world):
+            fids[i] = self.get_cand_fid(args=self.args, cand=eval(pending[i]))
+        if multi:
+            dev = self._ev.device if (self._ev is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+            mine = torch.from_numpy(np.nan_to_num(fids, nan=0.0)).to(dev)
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            for i in range(len(pending)):
+                fids[i] = float(parts[i % world][i])
+        for cand, fid in zip(pending, fids):
+            self.vis_dict[cand]['fid'] = float(fid)
+            logger.log('cand: {}, fid: {}'.format(cand, float(fid)))
 
     def is_legal_before_search(self, cand):
         return self._visit(cand)
@@ -264,6 +325,7 @@ class EvolutionSearcher(object):
                                                   m_prob=0.1)
         while self.epoch < self.max_epochs:
             logger.log('epoch = {}'.format(self.epoch))
+            self.flush_pending()
             self.update_top_k(self.candidates, k=self.select_num, key=lambda x: self.vis_dict[x]['fid'])
             self.update_top_k(self.candidates, k=50, key=lambda x: self.vis_dict[x]['fid'])
             logger.log('epoch = {} : top {} result'.format(self.epoch, len(self.keep_top_k[50])))
@@ -275,3 +337,4 @@ class EvolutionSearcher(object):
             self.candidates += self.get_cross(self.select_num, self.crossover_num)
             self.get_random(self.population_num)
             self.epoch += 1
+        self.flush_pending()

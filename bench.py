@@ -165,9 +165,14 @@ def main():
             ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in dom)
             fl = sum(f for _, _, f, _ in dom)
             achieved = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "r01", "pmc_dominant_kernel_traffic.json")
+            if os.path.exists(tp):  # HBM bytes per launch from separate rocprofv3 --pmc passes (see the file)
+                with open(tp) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)",
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": len(dom), "avg_launch_us": round(ms * 1e3 / len(dom), 2),
                     "avg_launch_gflop": round(fl / len(dom) / 1e9, 3),
                     "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
