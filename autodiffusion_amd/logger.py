@@ -4,13 +4,19 @@ import os
 import sys
 
 _file = None
+_dir = None
 
 
 def configure(dir=None, **_):
-    global _file
+    global _file, _dir
     if dir:
         os.makedirs(dir, exist_ok=True)
+        _dir = dir
         _file = open(os.path.join(dir, "log.txt"), "a")
+
+
+def get_dir():
+    return _dir
 
 
 def log(*args):

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Evolutionary timestep search on the HIP evaluation path -- the reference's search launchers in one CLI.
+
+Flags and defaults follow search_imagenet64_classifier_guidance.py:586-618 (classifier-guided) and
+search_uncondition_model.py (``--without_classifier True``): ``--time_step 4 --max_epochs 10
+--population_num 50 --mutation_num 25 --crossover_num 15 --m_prob 0.25 --use_ddim_init_x True`` ...
+Result lines ("epoch = i : top k result", "No.j [..] fid = ..") go to ``<save_dir>/log.txt`` unchanged.
+
+What this build needs from the user that the reference downloaded: the Inception pool3 feature extractor.
+``--features pkg.module:factory`` names a callable ``factory(device) -> (features, dim)`` where
+``features(uint8 NHWC device batch) -> fp32 [B, dim]``; ``--ref_path`` is an .npz with ``mu``, ``sigma``
+(written from the reference's pickled FIDStatistics).  ``--population_parallel True`` shards whole
+candidates over ranks; otherwise every candidate's images are sharded and the statistics pooled.
+"""
+import argparse
+import importlib
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from autodiffusion_amd import dist_util, logger  # noqa: E402
+from autodiffusion_amd.schedule import space_timesteps  # noqa: E402
+from autodiffusion_amd.script_util import (add_dict_to_argparser, args_to_dict, classifier_defaults,  # noqa: E402
+                                           create_classifier, create_model_and_diffusion,
+                                           model_and_diffusion_defaults)
+from autodiffusion_amd.search import EvolutionSearcher  # noqa: E402
+
+
+def create_argparser():
+    defaults = dict(
+        clip_denoised=True, num_samples=10000, batch_size=16, use_ddim=False, model_path="", save_dir="",
+        time_step=100, seed=0, deterministic=False, local_rank=0, max_epochs=20, select_num=10, population_num=50,
+        m_prob=0.1, crossover_num=25, mutation_num=35, classifier_path="", classifier_scale=1.0, max_fid=48.0,
+        thres=0.2, use_ddim_init_x=False, search_space="", ref_path="", MASTER_PORT="12344", init_x="",
+        without_classifier=False, features="", population_parallel=False,
+    )
+    defaults.update(model_and_diffusion_defaults())
+    defaults.update(classifier_defaults())
+    parser = argparse.ArgumentParser()
+    add_dict_to_argparser(parser, defaults)
+    return parser
+
+
+def build_search_space(args, diffusion):
+    if args.search_space == "":
+        return None
+    core = sorted(eval(args.search_space))
+    if args.use_ddim_init_x:
+        core += list(space_timesteps(diffusion.original_num_steps, ("ddim" if args.use_ddim else "") + str(args.time_step)))
+    r = int(diffusion.original_num_steps / 100)
+    space = []
+    for s in core:
+        space += list(range(max(s - r, 0), min(s + r, diffusion.original_num_steps)))
+    return sorted(set(space))
+
+
+def main(argv=None):
+    args = create_argparser().parse_args(argv)
+    os.environ.setdefault("MASTER_PORT", args.MASTER_PORT)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    random.seed(args.seed)
+    dist_util.setup_dist()
+    logger.configure(args.save_dir or None)
+    logger.log(str(args))
+    logger.log("creating model and diffusion...")
+    model, diffusion = create_model_and_diffusion(**args_to_dict(args, model_and_diffusion_defaults().keys()))
+    model.to(dist_util.dev())
+    if args.model_path:
+        model.load_state_dict(dist_util.load_state_dict(args.model_path, map_location="cpu"))
+    else:
+        model.randomize_(1234)
+    if args.use_fp16:
+        model.convert_to_fp16()
+    model.eval()
+    classifier = None
+    if not args.without_classifier:
+        classifier = create_classifier(**args_to_dict(args, classifier_defaults().keys()))
+        classifier.to(dist_util.dev())
+        if args.classifier_path:
+            classifier.load_state_dict(dist_util.load_state_dict(args.classifier_path, map_location="cpu"))
+        else:
+            classifier.randomize_(4321)
+    if not args.features:
+        raise SystemExit("--features pkg.module:factory is required (the Inception pool3 extractor is not bundled)")
+    mod, fn = args.features.split(":")
+    features, dim = getattr(importlib.import_module(mod), fn)(dist_util.dev())
+    search_space = build_search_space(args, diffusion)
+    if search_space is not None:
+        logger.log("search space: " + str(search_space))
+    t = time.time()
+    searcher = EvolutionSearcher(args, model=model, base_diffusion=diffusion, time_step=args.time_step,
+                                 classifier=classifier, search_space=search_space, features=features,
+                                 feature_dim=dim, population_parallel=args.population_parallel)
+    searcher.search()
+    logger.log("total searching time = {:.2f} hours".format((time.time() - t) / 3600))
+
+
+if __name__ == "__main__":
+    main()

@@ -88,3 +88,26 @@ def test_full_size_adm64_properties():
     a, b = ev.sample_batch(5, seed=11), ev.sample_batch(5, seed=11)
     assert a.shape == (5, 64, 64, 3) and a.dtype == torch.uint8 and torch.equal(a, b)
     assert not torch.equal(a, ev.sample_batch(5, seed=12))
+
+
+def test_sampling_cli_writes_the_reference_npz_format(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("classifier_sample", os.path.join(root, "scripts", "classifier_sample.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    flags = ("--image_size 64 --num_channels 32 --num_res_blocks 1 --channel_mult 1,2,2 --attention_resolutions 16 "
+             "--num_head_channels 32 --class_cond True --learn_sigma True --resblock_updown True --noise_schedule cosine "
+             "--use_dynamic_unet True --classifier_width 64 --classifier_depth 1 --use_ddim True --batch_size 4 "
+             "--num_samples 6").split()
+    out = mod.main(flags + ["--save_dir", str(tmp_path), "--use_timestep", "[153, 424, 926, 690]",
+                            "--skip_layers", "[[1],[],[0,5],[2,3]]"])
+    assert os.path.basename(out) == "samples_6x64x64x3.npz"
+    z = np.load(out)
+    assert z["arr_0"].shape == (6, 64, 64, 3) and z["arr_0"].dtype == np.uint8
+    assert z["arr_1"].shape == (6,) and z["arr_1"].dtype == np.int64
+    log = open(os.path.join(str(tmp_path), "log.txt")).read()
+    assert "sampling..." in log and "created 8 samples" in log and "sampling complete" in log
