@@ -35,7 +35,7 @@ class ConvArgs(C.Structure):
         ("aff_a", C.c_void_p), ("aff_b", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p),
         ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
         ("cout", C.c_int32), ("taps", C.c_int32), ("prologue", C.c_int32), ("out_mode", C.c_int32),
-        ("variant", C.c_int32), ("w_packed32", C.c_void_p),
+        ("variant", C.c_int32), ("out_stats", C.c_void_p), ("w_packed32", C.c_void_p),
     ]
 
 
@@ -56,6 +56,8 @@ SIGNATURES = {
     "adm_gn_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "adm_resample": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_conv": (_I, [C.POINTER(ConvArgs), _P]),
+    "adm_conv_stat_slabs": (_I, [C.POINTER(ConvArgs)]),
+    "adm_gn_finalize2": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P]),
     "adm_packed_weight_elems": (C.c_int64, [_I, _I, _I]),
     "adm_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "adm_packed_weight32_elems": (C.c_int64, [_I, _I, _I]),

@@ -40,6 +40,8 @@ constexpr unsigned OOB = 0x80000000u;  // buffer-load offset beyond num_records 
 struct ConvK {
   const uint16_t* in0; const uint16_t* in1; const uint16_t* w; const uint16_t* res;
   const float* bias; const float* aa; const float* ab; void* out;
+  float* stats;      // optional [N][stat_slabs][Cout][2] per-(image, slab, channel) sum / sum of squares of the OUTPUT
+  int stat_slabs;
   int N, H, W, C0, C1, Cout;
   int TH, TW, TI, tiles_x, tiles_y;
   int out_mode;
@@ -55,7 +57,10 @@ constexpr int conv_smem_bytes_k() { return 2 * halo_slots<NT, HALO>() * ROWB + 2
 // the epilogue restages one wave-row of the output tile (BM/WM pixels x BN channels, bf16) in the same LDS
 template <int NT, int BN, int HALO, int RPX>
 constexpr int conv_smem_bytes() {
-  return conv_smem_bytes_k<NT, HALO>() > RPX * (BN * 2 + 16) ? conv_smem_bytes_k<NT, HALO>() : RPX * (BN * 2 + 16);
+  constexpr int k = conv_smem_bytes_k<NT, HALO>();
+  constexpr int e = RPX * (BN * 2 + 16);   // output staging
+  constexpr int r = NT * 64;               // statistics reduction: [NT*8/BN rows][BN][2] floats
+  return (k > e ? k : e) > r ? (k > e ? k : e) : r;
 }
 
 __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -345,29 +350,67 @@ conv_kernel(const ConvK p) {
         }
       }
       __syncthreads();
-      for (int u = tid; u < RPX * SEGS; u += NT) {
-        const int pl = u / SEGS, sg = u % SEGS;
-        const int gch = nb * BN + sg * 8;
-        if (gch >= p.Cout) continue;
-        const int m = r * RPX + pl;
-        const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
-        const int n = img0 + ti;
-        if (n >= p.N) continue;
-        const long long pix = ((long long)n * p.H + y0 + rem / p.TW) * p.W + x0 + rem % p.TW;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + pl * EROW + sg * 16);
-        if (p.res) {
-          const uint4 rr = *reinterpret_cast<const uint4*>(p.res + pix * p.Cout + gch);
+      // each thread keeps ONE 16-byte channel segment and walks pixel rows, so that it can also
+      // accumulate the GroupNorm statistics of the values it stores (the consumer's adm_gn_partial pass
+      // over the whole tensor is then unnecessary)
+      constexpr int PR = NT / SEGS;           // pixel rows written per sweep
+      const int sg = tid % SEGS, prow = tid / SEGS;
+      const int gch = nb * BN + sg * 8;
+      float s1[8] = {}, s2[8] = {};
+      if (prow < PR && gch < p.Cout) {
+        for (int pl = prow; pl < RPX; pl += PR) {
+          const int m = r * RPX + pl;
+          const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
+          const int n = img0 + ti;
+          if (n >= p.N) continue;
+          const long long pix = ((long long)n * p.H + y0 + rem / p.TW) * p.W + x0 + rem % p.TW;
+          uint4 v = *reinterpret_cast<const uint4*>(smem + pl * EROW + sg * 16);
           uint32_t a4[4] = {v.x, v.y, v.z, v.w};
-          const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
+          if (p.res) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(p.res + pix * p.Cout + gch);
+            const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
-            const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
-            a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+            for (int q = 0; q < 4; ++q) {
+              const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
+              const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
+              a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+            }
+            v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
           }
-          v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+          *reinterpret_cast<uint4*>(outp + pix * p.Cout + gch) = v;
+          if (p.stats) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float lo = __uint_as_float(a4[q] << 16), hi = __uint_as_float(a4[q] & 0xffff0000u);
+              s1[2 * q] += lo; s2[2 * q] += lo * lo;
+              s1[2 * q + 1] += hi; s2[2 * q + 1] += hi * hi;
+            }
+          }
         }
-        *reinterpret_cast<uint4*>(outp + pix * p.Cout + gch) = v;
+      }
+      if (p.stats) {
+        // reduce the PR row-partials of every channel through LDS (fixed order: bitwise reproducible)
+        __syncthreads();  // staging buffer fully consumed
+        float* red = reinterpret_cast<float*>(smem);  // [PR][BN][2]
+        if (prow < PR) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            red[(prow * BN + sg * 8 + e) * 2 + 0] = s1[e];
+            red[(prow * BN + sg * 8 + e) * 2 + 1] = s2[e];
+          }
+        }
+        __syncthreads();
+        const int m0r = r * RPX;
+        const int n = img0 + m0r / (p.TH * p.TW);
+        if (tid < BN && nb * BN + tid < p.Cout && n < p.N) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int q = 0; q < PR; ++q) { t1 += red[(q * BN + tid) * 2]; t2 += red[(q * BN + tid) * 2 + 1]; }
+          // slab of this round inside its image: (tile of the image) * WM + r for one-image tiles, 0 otherwise
+          const int slab = p.TI == 1 ? (mt % (p.tiles_x * p.tiles_y)) * WM + r : 0;
+          float* dst = p.stats + (((long long)n * p.stat_slabs + slab) * p.Cout + nb * BN + tid) * 2;
+          dst[0] = t1;
+          dst[1] = t2;
+        }
       }
     }
     return;
@@ -744,6 +787,33 @@ int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
            k.H, k.W, BM);
 }
 
+
+// tiling variant (output-tile width): 5 = 192, 6 = 128 (8 waves); 1 = 128, 2 = 96, 4 = 64, 3 = 16 (4 waves).
+// Measured on MI355X (tools/conv_bench.py): the 8-wave tiles share one halo staging + prologue transform
+// among twice as many MFMAs and win whenever they pad <= 10 %; otherwise the 96-wide tile is the fastest
+// per useful column unless it pads > 15 % (then 64-wide); on the 128-pixel tiles of 8x8 maps the
+// 128-wide tile wins when it pads no more than the 96-wide one.
+int pick_variant(const adm_conv_args* a) {
+  if (a->variant != 0) return a->variant;
+  const int w192 = ((a->cout + 191) / 192) * 192, w128 = ((a->cout + 127) / 128) * 128;
+  const int w96 = ((a->cout + 95) / 96) * 96, w64 = ((a->cout + 63) / 64) * 64;
+  if (a->cout <= 16) return 3;
+  if (w192 * 10 <= a->cout * 11) return 5;
+  if (w128 * 10 <= a->cout * 11) return 6;
+  if (a->h * a->w <= 64) return (w128 <= w96) ? 1 : 2;
+  return (w96 * 0.85 <= w64) ? 2 : 4;
+}
+
+// slabs of the fused output statistics: one per (256-pixel tile, wave row) on maps >= 16x16, one per
+// image on 8x8 maps; 0 = not offered for this configuration
+int stat_slabs_for(const adm_conv_args* a, int variant) {
+  if (a->out_mode != 0 || variant == 7) return 0;
+  const int hw = a->h * a->w;
+  if (hw <= 64) return hw == 64 ? 1 : 0;
+  if (a->h < 16 || a->w < 16 || hw % 256 != 0) return 0;
+  return (hw / 256) * (variant == 3 ? 4 : 2);
+}
+
 }  // namespace
 
 extern "C" int64_t adm_packed_weight_elems(int cout, int cin, int taps) {
@@ -780,6 +850,11 @@ extern "C" int adm_pack_conv_weight32(const float* w, adm_bf16* out, int cout, i
   return adm_check_launch("adm_pack_conv_weight32");
 }
 
+extern "C" int adm_conv_stat_slabs(const adm_conv_args* a) {
+  if (!a) return 0;
+  return stat_slabs_for(a, pick_variant(a));
+}
+
 extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE(a, ADM_E_ARG, "adm_conv: null args");
   ADM_REQUIRE(a->in0 && a->w_packed && a->bias && a->out, ADM_E_ARG, "adm_conv: null pointer");
@@ -801,26 +876,17 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ConvK k{};
   k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;
   k.bias = a->bias; k.aa = a->aff_a; k.ab = a->aff_b; k.out = a->out;
+  k.stats = a->out_stats; k.stat_slabs = 0;
   k.N = a->n; k.H = a->h; k.W = a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
   k.out_mode = a->out_mode;
   k.ntiles16 = (a->cout + 15) / 16;
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
 
-  // tiling variant (output-tile width): 5 = 192, 6 = 128 (8 waves); 1 = 128, 2 = 96, 4 = 64, 3 = 16 (4 waves).
-  // Measured on MI355X (tools/conv_bench.py): the 8-wave 192-wide tile shares one halo staging + prologue
-  // transform among twice as many MFMAs and wins whenever it pads <= 10 %; otherwise the 96-wide tile is
-  // the fastest per useful column unless it pads > 15 % (then 64-wide); on the 128-pixel tiles of 8x8
-  // maps the 128-wide tile wins when it pads no more than the 96-wide one.
-  int variant = a->variant;
-  if (variant == 0) {
-    const int w192 = ((a->cout + 191) / 192) * 192, w128 = ((a->cout + 127) / 128) * 128;
-    const int w96 = ((a->cout + 95) / 96) * 96, w64 = ((a->cout + 63) / 64) * 64;
-    if (a->cout <= 16) variant = 3;
-    else if (w192 * 10 <= a->cout * 11) variant = 5;
-    else if (w128 * 10 <= a->cout * 11) variant = 6;
-    else if (a->h * a->w <= 64) variant = (w128 <= w96) ? 1 : 2;
-    else variant = (w96 * 0.85 <= w64) ? 2 : 4;
+  const int variant = pick_variant(a);
+  if (a->out_stats) {
+    k.stat_slabs = stat_slabs_for(a, variant);
+    ADM_REQUIRE(k.stat_slabs > 0, ADM_E_SHAPE, "adm_conv: fused output statistics are not offered for this shape / variant");
   }
   if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
     ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out");

@@ -126,20 +126,27 @@ gn_partial_kernel(const uint16_t* __restrict__ in0, int c0, const uint16_t* __re
 
 // grid (n). Combine slabs and the channels of each of the 32 groups in double, emit the affine.
 __global__ void __launch_bounds__(256)
-gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const float* __restrict__ part1, int c1, int slabs1,
+                   const float* __restrict__ gamma, const float* __restrict__ beta,
                    const float* __restrict__ film, int film_stride, float* __restrict__ aff_a,
-                   float* __restrict__ aff_b, float* __restrict__ stats, int c, int hw, int slabs, float eps) {
+                   float* __restrict__ aff_b, float* __restrict__ stats, int hw, float eps) {
+  const int c = c0 + c1;
   __shared__ float gmean[32], grstd[32];
   const int img = blockIdx.x;
   const int cpg = c / 32;
   // one wave-quarter per group: thread t handles group t/8, strided over (slab, channel-in-group)
   const int grp = threadIdx.x / 8, sub = threadIdx.x % 8;
   double s = 0.0, ss = 0.0;
-  for (int i = sub; i < slabs * cpg; i += 8) {
-    const int sl = i / cpg, ch = grp * cpg + i % cpg;
-    const float* p = partial + ((((long long)img * slabs + sl) * c) + ch) * 2;
-    s += (double)p[0];
-    ss += (double)p[1];
+  for (int j = sub; j < cpg; j += 8) {  // channels of the group; each may live in either part of the concat
+    const int ch = grp * cpg + j;
+    const bool first = ch < c0;
+    const float* base = first ? part0 : part1;
+    const int cs = first ? c0 : c1, cl = first ? ch : ch - c0, slabs = first ? slabs0 : slabs1;
+    for (int sl = 0; sl < slabs; ++sl) {
+      const float* p = base + ((((long long)img * slabs + sl) * cs) + cl) * 2;
+      s += (double)p[0];
+      ss += (double)p[1];
+    }
   }
 #pragma unroll
   for (int off = 4; off >= 1; off >>= 1) {
@@ -275,9 +282,23 @@ extern "C" int adm_gn_finalize(const float* partial, const float* gamma, const f
   ADM_REQUIRE(partial && gamma && beta && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize: null pointer");
   ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0, ADM_E_SHAPE, "adm_gn_finalize: bad shape");
   ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize: film_stride < 2*c");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta, film,
-                     film_stride, aff_a, aff_b, stats, c, hw, slabs, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
+                     (const float*)nullptr, 0, 0, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps);
   return adm_check_launch("adm_gn_finalize");
+}
+
+extern "C" int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const float* partial1, int c1, int slabs1,
+                                const float* gamma, const float* beta, const float* film, int film_stride,
+                                float* aff_a, float* aff_b, float* stats, int n, int hw, float eps, void* stream) {
+  ADM_REQUIRE(partial0 && gamma && beta && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize2: null pointer");
+  ADM_REQUIRE((partial1 != nullptr) == (c1 > 0), ADM_E_ARG, "adm_gn_finalize2: partial1/c1 mismatch");
+  const int c = c0 + c1;
+  ADM_REQUIRE(n > 0 && c0 > 0 && c % 32 == 0 && hw > 0 && slabs0 > 0 && (c1 == 0 || slabs1 > 0), ADM_E_SHAPE,
+              "adm_gn_finalize2: bad shape");
+  ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize2: film_stride < 2*c");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial0, c0, slabs0, partial1, c1,
+                     slabs1, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps);
+  return adm_check_launch("adm_gn_finalize2");
 }
 
 extern "C" int adm_resample(const adm_bf16* in, const float* aff_a, const float* aff_b, adm_bf16* out, int n, int h,

@@ -18,6 +18,9 @@ from ._lib import AdmError, ConvArgs, StepCoefs, check
 BF16 = torch.bfloat16
 GN_EPS = 1e-5
 
+# conv epilogues accumulate the GroupNorm partial sums of their output (consumed by gn_affine)
+USE_FUSED_STATS = True
+
 # bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
 # every conv launch appends (start_event, end_event, algorithmic_flops, (variant, taps, big_map, prologue)).
 CONV_PROFILE = None
@@ -139,22 +142,31 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
     c1 = 0 if x1 is None else x1.shape[3]
     c, hw = c0 + c1, h * w
     lib = _lib.load()
-    slabs = gn_slabs(hw)
-    if partial is None:
-        partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
     a = torch.empty((n, c), dtype=torch.float32, device=x0.device)
     b = torch.empty((n, c), dtype=torch.float32, device=x0.device)
-    check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, _ptr(x1, BF16, "x1"), c1, _ptr(partial), n, hw, slabs, _stream()),
-          "adm_gn_partial")
     film_ptr = None
     if film is not None:
         if film.dtype != torch.float32 or not film.is_cuda:
             raise AdmError("film must be a float32 device tensor")
         film_ptr = film.data_ptr()
     stats = torch.empty((n, 32, 2), dtype=torch.float32, device=x0.device) if want_stats else None
-    check(lib.adm_gn_finalize(_ptr(partial), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
-                              film_ptr, film_stride, _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, GN_EPS,
-                              _stream()), "adm_gn_finalize")
+    fused0 = getattr(x0, "_adm_stats", None)
+    fused1 = getattr(x1, "_adm_stats", None) if x1 is not None else None
+    if USE_FUSED_STATS and fused0 is not None and (x1 is None or fused1 is not None):
+        # the producing conv already accumulated sum / sum-of-squares of this tensor in its epilogue
+        p1, s1 = (fused1 if fused1 is not None else (None, 0))
+        check(lib.adm_gn_finalize2(_ptr(fused0[0]), c0, fused0[1], _ptr(p1), c1, s1, _ptr(gamma, torch.float32, "gamma"),
+                                   _ptr(beta, torch.float32, "beta"), film_ptr, film_stride, _ptr(a), _ptr(b),
+                                   _ptr(stats), n, hw, GN_EPS, _stream()), "adm_gn_finalize2")
+    else:
+        slabs = gn_slabs(hw)
+        if partial is None:
+            partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
+        check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, _ptr(x1, BF16, "x1"), c1, _ptr(partial), n, hw, slabs,
+                                 _stream()), "adm_gn_partial")
+        check(lib.adm_gn_finalize(_ptr(partial), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+                                  film_ptr, film_stride, _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, GN_EPS,
+                                  _stream()), "adm_gn_finalize")
     if want_stats:
         return a, b, stats
     return a, b
@@ -206,7 +218,7 @@ def pack_conv_weight32(w):
 
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
-         out_f32_nchw=False, variant=0, out=None, w_packed32=None):
+         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): bf16 NHWC.  Returns bf16 NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].
@@ -233,6 +245,15 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
         if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw:
             variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
     a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
+    a.variant = variant
+    a.taps, a.out_mode = taps, int(out_f32_nchw)
+    fused = None
+    if want_stats and USE_FUSED_STATS:
+        slabs = _lib.load().adm_conv_stat_slabs(C.byref(a))
+        if slabs > 0:
+            fused = (torch.empty((n, slabs, cout, 2), dtype=torch.float32, device=dev), slabs)
+            a.out_stats = fused[0].data_ptr()
+            out._adm_stats = fused
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

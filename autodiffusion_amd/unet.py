@@ -248,7 +248,7 @@ class AdmNet(HipModule):
         if skipped:  # dynamic_unet.py:245-250: body bypassed, x_upd + skip_connection kept
             xs = ops.resample(x0, mode) if mode else x0
             if s.has_skip_conv:
-                return ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=x1)
+                return ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=x1, want_stats=True)
             return xs
         st1 = st2 = None
         if tape is not None:
@@ -260,10 +260,10 @@ class AdmNet(HipModule):
             assert x1 is None
             h_in = ops.resample(x0, mode, aff1)
             xs = ops.resample(x0, mode)
-            h = ops.conv(h_in, d["w1"], d["c1b"], s.cout, 9)
+            h = ops.conv(h_in, d["w1"], d["c1b"], s.cout, 9, want_stats=True)
             xs1 = None
         else:
-            h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True)
+            h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True, want_stats=True)
             xs, xs1 = x0, x1
         off = pr.film_off[s.prefix]
         if tape is not None:
@@ -277,7 +277,7 @@ class AdmNet(HipModule):
             res = ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=xs1)
         else:
             res = xs
-        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res)
+        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True)
 
     def _attention(self, pr, s: AttnSpec, x, skipped, tape=None):
         if skipped:  # dynamic_unet.py:316-318
@@ -295,14 +295,14 @@ class AdmNet(HipModule):
             tape.append(("attn", s, dict(x=x, aff=aff, st=st, qkv=qkv, a=a, lse=lse)))
         else:
             a = ops.attention(qkv.view(n, hh * ww, 3 * c), s.num_heads, s.new_order)
-        return ops.conv(a.view(n, hh, ww, c), d["wproj"], d["bproj"], c, 1, res=x)
+        return ops.conv(a.view(n, hh, ww, c), d["wproj"], d["bproj"], c, 1, res=x, want_stats=True)
 
     def _run_seq(self, pr, seq, h, skip, film, skip_ids, x_nchw=None, tape=None):
         first = True
         for blk in seq:
             if isinstance(blk, StemSpec):
                 d = pr.blocks[blk.prefix]
-                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32), d["w"], d["b"], blk.cout, 9)
+                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32), d["w"], d["b"], blk.cout, 9, want_stats=True)
                 if tape is not None:
                     tape.append(("stem", blk, {}))
             elif isinstance(blk, ResBlockSpec):

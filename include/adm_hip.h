@@ -116,6 +116,11 @@ int adm_gn_finalize(const float* partial, const float* gamma, const float* beta,
                     const float* film, int film_stride, float* aff_a, float* aff_b,
                     float* stats /* nullable: [N][32][2] = (mean, rstd), kept for adm_gn_bwd_* */,
                     int n, int c, int hw, int slabs, float eps, void* stream);
+/* Same for a virtual concat whose two parts carry their own partial sums (e.g. from adm_conv's out_stats):
+ * partial0 fp32 [N][slabs0][c0][2], partial1 fp32 [N][slabs1][c1][2] (NULL / 0 when there is one part). */
+int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const float* partial1, int c1, int slabs1,
+                     const float* gamma, const float* beta, const float* film, int film_stride,
+                     float* aff_a, float* aff_b, float* stats, int n, int hw, float eps, void* stream);
 
 /* h_upd / x_upd of an up/down ResBlock (unet.py:190-195, 237-242):
  * out = resample(act(a*in + b)), act = SiLU when aff_a != NULL, identity copy otherwise.
@@ -143,11 +148,16 @@ typedef struct adm_conv_args {
   int32_t prologue;  /* 0,1,2  */
   int32_t out_mode;  /* 0,1    */
   int32_t variant;   /* tiling variant, 0 = auto */
+  float* out_stats;  /* optional: fp32 [N][slabs][cout][2] = per-(image, slab, channel) sum and sum of squares of
+                        the bf16 OUTPUT, accumulated in the epilogue (slabs = adm_conv_stat_slabs(args)); the
+                        consumer's GroupNorm then needs no adm_gn_partial pass over the tensor */
   const adm_bf16* w_packed32; /* optional: the same weight in the 32x32x16 fragment order
                                  (adm_pack_conv_weight32); enables variant 7, the v_mfma_f32_32x32x16_bf16
                                  kernel for 3x3 convs on maps >= 16x16 */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
+/* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */
+int adm_conv_stat_slabs(const adm_conv_args* args_host);
 
 /* fp32 [cout, cin, kh, kw] (kh*kw = taps) -> bf16 fragment-ordered image
  * [cin/32][taps][ceil(cout/16)][64 lanes][8]; out must hold adm_packed_weight_elems().   */

@@ -244,3 +244,35 @@ def test_attention_softmax_is_stable_for_large_logits(ops):
     got = got.float().cpu().permute(0, 2, 1)
     assert torch.isfinite(got).all()
     assert_close_bf16(got, ref, "attention large logits")
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,taps,variant", [(3, 16, 64, 192, 9, 0), (2, 32, 32, 96, 9, 0), (5, 8, 64, 192, 9, 0),
+                                                         (2, 64, 32, 64, 1, 0), (2, 16, 32, 128, 9, 6), (3, 8, 64, 128, 1, 0)])
+def test_conv_fused_output_statistics_feed_groupnorm(ops, n, hw, cin, cout, taps, variant):
+    """The sums accumulated in the conv epilogue must give the same GroupNorm affine as a separate pass."""
+    k = 3 if taps == 9 else 1
+    x = nhwc_dev(bf(rnd((n, cin, hw, hw), 1)))
+    wp = ops.pack_conv_weight((rnd((cout, cin, k, k), 2, (cin * taps) ** -0.5)).to(DEV))
+    res = nhwc_dev(bf(rnd((n, cout, hw, hw), 3)))
+    y = ops.conv(x, wp, (0.1 * rnd((cout,), 4)).to(DEV), cout, taps, res=res, variant=variant, want_stats=True)
+    assert getattr(y, "_adm_stats", None) is not None
+    gamma, beta = (1 + 0.2 * rnd((cout,), 5)).to(DEV), (0.1 * rnd((cout,), 6)).to(DEV)
+    a1, b1 = ops.gn_affine(y, gamma, beta)                       # fused statistics
+    ops.USE_FUSED_STATS = False
+    try:
+        a2, b2 = ops.gn_affine(y, gamma, beta)                   # separate adm_gn_partial pass
+    finally:
+        ops.USE_FUSED_STATS = True
+    torch.testing.assert_close(a1, a2, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(b1, b2, rtol=2e-4, atol=2e-5)
+    # virtual concat of two tensors that both carry fused statistics
+    y2 = ops.conv(x, wp, torch.zeros(cout, device=DEV), cout, taps, variant=variant, want_stats=True)
+    g2, be2 = torch.cat([gamma, gamma]), torch.cat([beta, beta])
+    a1, b1 = ops.gn_affine(y, g2, be2, y2)
+    ops.USE_FUSED_STATS = False
+    try:
+        a2, b2 = ops.gn_affine(y, g2, be2, y2)
+    finally:
+        ops.USE_FUSED_STATS = True
+    torch.testing.assert_close(a1, a2, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(b1, b2, rtol=2e-4, atol=2e-5)

@@ -111,3 +111,6 @@ def test_sampling_cli_writes_the_reference_npz_format(tmp_path):
     assert z["arr_1"].shape == (6,) and z["arr_1"].dtype == np.int64
     log = open(os.path.join(str(tmp_path), "log.txt")).read()
     assert "sampling..." in log and "created 8 samples" in log and "sampling complete" in log
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
