@@ -218,14 +218,32 @@ conv_kernel(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) dst[j] = bufload16(rsw, wofs[j], (unsigned)step * wstep);
   };
+  // LDS fragment reads run AFD tiles ahead of the MFMAs that consume them (the compiler otherwise issues
+  // one ds_read_b128, waits lgkmcnt(0), then its TN MFMAs: the read latency was exposed TM times per tap)
   auto mfma_tap = [&](const unsigned char* hp, const uint4 (&w)[TN]) {
+    constexpr int AFD = TM < 4 ? TM : 4;
     const unsigned char* hl = hp + alane;
+    // scheduling fence: the staging work issued above (loads, prologue transform, LDS writes and their
+    // own LDS reads) stays out of the pinned read/MFMA pipeline below
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 af[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {  // pixel tile outer: one activation fragment live at a time
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
+    for (int i = 0; i < AFD; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i + AFD < TM) af[i + AFD] = *reinterpret_cast<const bf16x8*>(hl + aoff[i + AFD]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af[i], acc[i][j], 0, 0, 0);
+    }
+    // pin the interleave in the emitted code: AFD reads up front, then {1 read, TN MFMAs} per pixel tile
+    // (LLVM otherwise sinks every read next to its use to save registers)
+#pragma unroll
+    for (int i = 0; i < AFD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i + AFD < TM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
     }
   };
 
