@@ -44,7 +44,7 @@ def main():
         x1 = (torch.randn(n, hw, hw, c1, device=DEV)).to(torch.bfloat16) if c1 else None
         w = torch.randn(cout, cin, k, k, device=DEV) * (cin * taps) ** -0.5
         wp = ops.pack_conv_weight(w)
-        wp32 = ops.pack_conv_weight32(w) if (taps == 9 and hw >= 16) else None
+        wp32 = ops.pack_conv_weight32(w) if (variant == 7 and taps == 9 and hw >= 16) else None
         if variant == 7 and wp32 is None:
             continue
         b = torch.randn(cout, device=DEV) * 0.1
