@@ -29,8 +29,11 @@ struct AttnK {
   float scale_log2;  // log2(e) / sqrt(D)
 };
 
+// (256, 2): two waves per SIMD caps the kernel at 256 registers, which also makes hipcc keep the MFMA
+// accumulators in VGPRs -- with the default bound it parked them in AGPRs and spent ~160 v_accvgpr_read/write
+// per key tile moving S^T out for the softmax and O^T through the rescale.
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, D <= 64 ? 2 : 0)
 attn_kernel(const AttnK p) {
   constexpr int KS = D / 32;   // k-steps of QK^T
   constexpr int DT = D / 16;   // d tiles of the output
@@ -86,37 +89,54 @@ attn_kernel(const AttnK p) {
     const uint16_t* Kc = Ks[cur];
     const uint16_t* Vc = Vs[cur];
 
-    // ---- S^T = K . Q^T  (4 key tiles x 2 query tiles)
+    // ---- S^T = K . Q^T  (4 key tiles x 2 query tiles).  All K fragments of the tile are requested first
+    //      (scheduling fences keep hipcc from sinking each LDS read next to its two MFMAs, which exposed the
+    //      read latency 8 times per tile); the V^T fragments are requested right after the S MFMAs so that
+    //      their latency hides under the softmax VALU work.
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 kfr[4][KS];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        kfr[kt][ks] = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 st[4][2];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kt][qt], 0, 0, 0);
-      }
+          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 vfr[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) vfr[dt][kb] = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- online softmax (per query column)
     const bool ragged = k0 + KT > p.T;
     bf16x8 pf[2][2];  // [query tile][32-key block]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float mx = -1e30f;
+      if (ragged) {  // only the last tile of a sequence whose length is not a multiple of 64
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + lq * 4 + r >= p.T) st[kt][qt][r] = -1e30f;
+      }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = st[kt][qt][r];
-          if (ragged && k0 + kt * 16 + lq * 4 + r >= p.T) s = -1e30f;
-          st[kt][qt][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][qt][r]);
+      mx = adm_quarter_max(mx);
       const float m_new = fmaxf(m_run[qt], mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.scale_log2);
       const float mneg = -m_new * p.scale_log2;
@@ -145,17 +165,15 @@ attn_kernel(const AttnK p) {
       }
     }
     // ---- O^T += V^T . P^T ; contraction slot k = 8*lq + e  <->  key kb*32 + 16*(e>>2) + 4*lq + (e&3);
-    //      V^T fragments come from the row-major tile through the transposing LDS read
+    //      V^T fragments came from the row-major tile through the transposing LDS read
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8 vf = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kb], oacc[dt][qt], 0, 0, 0);
-      }
-    }
+          oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
     if (next) {
       kr.store(Ks[cur ^ 1], KROW, tid);
       vr.store(Vs[cur ^ 1], KROW, tid);
@@ -166,9 +184,7 @@ attn_kernel(const AttnK p) {
   // ---- normalise and store: lane holds d = dt*16 + 4*lq .. +3 of query lc
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = adm_quarter_sum(l_run[qt]);
     const float inv = 1.0f / l;
     const int q = qbase + qt * 16 + lc;
     if (q >= p.T) continue;

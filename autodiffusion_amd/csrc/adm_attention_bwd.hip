@@ -56,7 +56,7 @@ delta_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout
 
 // ------------------------------------------------------------------------------------ dQ
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 attn_dq_kernel(const AttnBwdK p) {
   constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE;
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][TT * KROW];
@@ -178,7 +178,7 @@ attn_dq_kernel(const AttnBwdK p) {
 
 // ------------------------------------------------------------------------------------ dK, dV
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 attn_dkv_kernel(const AttnBwdK p) {
   constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE;
   __shared__ __attribute__((aligned(16))) uint16_t Qs[2][TT * KROW];

@@ -44,3 +44,20 @@ struct AdmTileRegs {
     }
   }
 };
+
+// Reductions over the 4 lane quarters that share one MFMA column (lanes l, l^16, l^32, l^48) with the VALU
+// row/half swaps of gfx950 instead of ds_bpermute shuffles: v_permlane16_swap exchanges odd 16-lane rows of
+// the first operand with even rows of the second, v_permlane32_swap the upper half with the lower half.
+typedef __attribute__((ext_vector_type(2))) unsigned int adm_u32x2;
+__device__ __forceinline__ float adm_quarter_max(float x) {
+  adm_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float adm_quarter_sum(float x) {
+  adm_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
