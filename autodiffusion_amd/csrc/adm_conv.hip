@@ -44,24 +44,46 @@ struct ConvK {
   int stat_slabs;
   int N, H, W, C0, C1, Cout;
   int TH, TW, TI, tiles_x, tiles_y;
+  int tw_shift, thw_shift;   // log2(TW), log2(TH*TW)
   int out_mode;
   int ntiles16, nblocks_n;
   unsigned wbytes;
 };
+
+// output-statistics slabs per tile: a 128-pixel tile is two 8x8 images (or two halves of one image)
+template <int BM>
+constexpr int stat_groups() { return BM == 128 ? 2 : 1; }
 
 // every lane of every staging pass owns an LDS slot: the halo capacity is rounded up to whole passes
 template <int NT, int HALO>
 constexpr int halo_slots() { return ((HALO * 4 + NT - 1) / NT) * NT / 4; }
 template <int NT, int HALO>
 constexpr int conv_smem_bytes_k() { return 2 * halo_slots<NT, HALO>() * ROWB + 2 * TI_MAX * 64 * 4; }
-// the epilogue restages one wave-row of the output tile (BM/WM pixels x BN channels, bf16) in the same LDS
-template <int NT, int BN, int HALO, int RPX>
+// the epilogue restages the whole output tile (BM pixels x BN channels, bf16) in the same LDS
+template <int NT, int BN, int HALO, int BM>
 constexpr int conv_smem_bytes() {
   constexpr int k = conv_smem_bytes_k<NT, HALO>();
-  constexpr int e = RPX * (BN * 2 + 16);   // output staging
+  constexpr int e = BM * (BN * 2 + 16);    // output staging
   constexpr int r = NT * 64;               // statistics reduction: [NT*8/BN rows][BN][2] floats
   return (k > e ? k : e) > r ? (k > e ? k : e) : r;
 }
+
+#ifdef ADM_CONV_TIMING
+// debug build only (make timing): per-block phase time stamps of conv_kernel, read by tools/conv_timing.py
+__device__ unsigned long long adm_conv_timing_buf[16 * 16384];
+#define ADM_TSTAMP(k)                                                                         \
+  do {                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                             \
+      adm_conv_timing_buf[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();               \
+      if ((k) == 0) {                                                                         \
+        adm_conv_timing_buf[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  \
+        adm_conv_timing_buf[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg((31 << 11) | 20); \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+#else
+#define ADM_TSTAMP(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
@@ -80,11 +102,13 @@ conv_kernel(const ConvK p) {
   constexpr int PASSES = (HALO * 4 + NT - 1) / NT;
   constexpr int HSLOT = halo_slots<NT, HALO>();
   constexpr int PAD = TAPS == 9 ? 1 : 0;
+  constexpr int SGROUPS = stat_groups<WM * TM * 16>();  // statistics slabs per tile
   static_assert(TAPS == 1 || PASSES <= TAPS - 1, "halo passes must fit in the taps of one chunk");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const halo = smem;                       // [2][HSLOT * ROWB]
   float* const abuf = reinterpret_cast<float*>(smem + 2 * HSLOT * ROWB);
+  ADM_TSTAMP(0);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,8 +116,13 @@ conv_kernel(const ConvK p) {
   const int wm = wave / WN, wn = wave % WN;
   const int lc = lane & 15, lq = lane >> 4;
 
-  const int nb = blockIdx.x % p.nblocks_n;
-  const int mt = blockIdx.x / p.nblocks_n;
+  // XCD-aware tile order: the dispatcher deals consecutive blocks round-robin to the 8 XCDs (each with its own
+  // L2), so block b runs logical tile (b % 8) * ceil-share + b / 8: one XCD then owns a contiguous run of
+  // tiles -- all Cout blocks of a pixel tile and its spatial neighbours (shared halo rows) hit the same L2
+  const unsigned tshare = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;
+  const int ltile = (int)(xcd * tshare + min(xcd, trem) + (blockIdx.x >> 3));
+  const int nb = ltile % p.nblocks_n;
+  const int mt = ltile / p.nblocks_n;
   const int HW2 = p.TW + 2 * PAD;
   const int HPI = (p.TH + 2 * PAD) * HW2;
   const int HP = p.TI * HPI;
@@ -258,6 +287,7 @@ conv_kernel(const ConvK p) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) halo_write(h0[ps], ps, 0);
   }
+  ADM_TSTAMP(1);
 
   if constexpr (TAPS == 9) {
     // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
@@ -340,97 +370,114 @@ conv_kernel(const ConvK p) {
     }
   }
 
+  ADM_TSTAMP(2);
   // ---- epilogue: lane (lc, lq) holds channels 4*lq..4*lq+3 of tile j for pixel lc of tile i
   if (p.out_mode == 0) {
-    // bf16 NHWC: per wave-row of the tile, stage (acc + bias) as bf16 in LDS, then write whole pixel rows
-    // with 16-byte lanes (BN*2 contiguous bytes per pixel) and add the residual with equally coalesced
-    // loads -- fragment-shaped 8-byte stores touch 16 cache lines per instruction and dominated 1x1 convs
-    constexpr int RPX = TM * 16;            // pixels per round (= one wm row of waves)
+    // bf16 NHWC.  The block is alone on its CU (8 waves x > 128 VGPRs), so nothing else hides this phase:
+    // the whole tile (acc + bias, bf16) is staged in LDS in ONE round and leaves as whole pixel rows with
+    // 16-byte lanes (BN*2 contiguous bytes per pixel); the residual operand is fetched with the same
+    // coalesced shape BEFORE the staging barrier, so that its latency overlaps the LDS round trip.
+    // (Fragment-shaped 8-byte stores touch 16 cache lines per instruction and dominated 1x1 convs.)
+    constexpr int BM = WM * TM * 16;
     constexpr int EROW = BN * 2 + 16;       // staged bytes per pixel
     constexpr int SEGS = BN / 8;            // 16-byte segments per pixel
+    constexpr int PR = NT / SEGS;           // pixel rows written per sweep
+    constexpr int RG = BM / SGROUPS;        // pixel rows per statistics group
+    constexpr int NIT = (RG + PR - 1) / PR; // sweeps per group
     uint16_t* const outp = reinterpret_cast<uint16_t*>(p.out);
-    for (int r = 0; r < WM; ++r) {
-      __syncthreads();
-      if (wm == r) {
+    // each thread keeps ONE 16-byte channel segment and walks pixel rows, so that it can also accumulate
+    // the GroupNorm statistics of the values it stores (the consumer's adm_gn_partial pass is then unnecessary)
+    const int sg = tid % SEGS, prow = tid / SEGS;
+    const int gch = nb * BN + sg * 8;
+    const bool act = prow < PR && gch < p.Cout;
+    const int thw_mask = (1 << p.thw_shift) - 1, tw_mask = (1 << p.tw_shift) - 1;
+    long long eoff[SGROUPS][NIT];           // element offset of the thread's segment in out / res, or -1
+    uint4 rr[SGROUPS][NIT];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int ch0 = (wn * TN + j) * 16 + lq * 4;
-          const int gch = nb * BN + ch0;
-          float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (gch + 3 < p.Cout) bs = *reinterpret_cast<const float4*>(p.bias + gch);
+    for (int g = 0; g < SGROUPS; ++g)
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            uint2 o;
-            o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0] + bs.x) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1] + bs.y) << 16);
-            o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2] + bs.z) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3] + bs.w) << 16);
-            *reinterpret_cast<uint2*>(smem + (i * 16 + lc) * EROW + ch0 * 2) = o;
+      for (int k = 0; k < NIT; ++k) {
+        const int ml = prow + k * PR, m = g * RG + ml;
+        const int ti = m >> p.thw_shift, rem = m & thw_mask;
+        const int n = img0 + ti;
+        const long long pix = ((long long)n * p.H + y0 + (rem >> p.tw_shift)) * p.W + x0 + (rem & tw_mask);
+        eoff[g][k] = (act && ml < RG && n < p.N) ? pix * p.Cout + gch : -1;
+        rr[g][k] = make_uint4(0, 0, 0, 0);
+        if (p.res && eoff[g][k] >= 0) rr[g][k] = *reinterpret_cast<const uint4*>(p.res + eoff[g][k]);
+      }
+    __syncthreads();  // every wave is done with the halo buffers
+    ADM_TSTAMP(3);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ch0 = (wn * TN + j) * 16 + lq * 4;
+      const int bch = nb * BN + ch0;
+      float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bch + 3 < p.Cout) bs = *reinterpret_cast<const float4*>(p.bias + bch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        uint2 o;
+        o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0] + bs.x) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1] + bs.y) << 16);
+        o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2] + bs.z) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3] + bs.w) << 16);
+        *reinterpret_cast<uint2*>(smem + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
+      }
+    }
+    __syncthreads();
+    ADM_TSTAMP(4);
+    float s1[SGROUPS][8] = {}, s2[SGROUPS][8] = {};
+#pragma unroll
+    for (int g = 0; g < SGROUPS; ++g)
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        if (eoff[g][k] < 0) continue;
+        const int m = g * RG + prow + k * PR;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + m * EROW + sg * 16);
+        uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+        if (p.res) {
+          const uint32_t r4[4] = {rr[g][k].x, rr[g][k].y, rr[g][k].z, rr[g][k].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
+            const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
+            a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
           }
+          v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+        }
+        *reinterpret_cast<uint4*>(outp + eoff[g][k]) = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(a4[q] << 16), hi = __uint_as_float(a4[q] & 0xffff0000u);
+          s1[g][2 * q] += lo; s2[g][2 * q] += lo * lo;
+          s1[g][2 * q + 1] += hi; s2[g][2 * q + 1] += hi * hi;
         }
       }
-      __syncthreads();
-      // each thread keeps ONE 16-byte channel segment and walks pixel rows, so that it can also
-      // accumulate the GroupNorm statistics of the values it stores (the consumer's adm_gn_partial pass
-      // over the whole tensor is then unnecessary)
-      constexpr int PR = NT / SEGS;           // pixel rows written per sweep
-      const int sg = tid % SEGS, prow = tid / SEGS;
-      const int gch = nb * BN + sg * 8;
-      float s1[8] = {}, s2[8] = {};
-      if (prow < PR && gch < p.Cout) {
-        for (int pl = prow; pl < RPX; pl += PR) {
-          const int m = r * RPX + pl;
-          const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
-          const int n = img0 + ti;
-          if (n >= p.N) continue;
-          const long long pix = ((long long)n * p.H + y0 + rem / p.TW) * p.W + x0 + rem % p.TW;
-          uint4 v = *reinterpret_cast<const uint4*>(smem + pl * EROW + sg * 16);
-          uint32_t a4[4] = {v.x, v.y, v.z, v.w};
-          if (p.res) {
-            const uint4 rr = *reinterpret_cast<const uint4*>(p.res + pix * p.Cout + gch);
-            const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
+    ADM_TSTAMP(5);
+    if (p.stats) {
+      // reduce the PR row-partials of every channel through LDS (fixed order: bitwise reproducible)
+      float* red = reinterpret_cast<float*>(smem);  // [PR][BN][2]
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
-              const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
-              a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
-            }
-            v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
-          }
-          *reinterpret_cast<uint4*>(outp + pix * p.Cout + gch) = v;
-          if (p.stats) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float lo = __uint_as_float(a4[q] << 16), hi = __uint_as_float(a4[q] & 0xffff0000u);
-              s1[2 * q] += lo; s2[2 * q] += lo * lo;
-              s1[2 * q + 1] += hi; s2[2 * q + 1] += hi * hi;
-            }
-          }
-        }
-      }
-      if (p.stats) {
-        // reduce the PR row-partials of every channel through LDS (fixed order: bitwise reproducible)
-        __syncthreads();  // staging buffer fully consumed
-        float* red = reinterpret_cast<float*>(smem);  // [PR][BN][2]
+      for (int g = 0; g < SGROUPS; ++g) {
+        __syncthreads();  // staging buffer (or the previous group's partials) fully consumed
         if (prow < PR) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            red[(prow * BN + sg * 8 + e) * 2 + 0] = s1[e];
-            red[(prow * BN + sg * 8 + e) * 2 + 1] = s2[e];
+            red[(prow * BN + sg * 8 + e) * 2 + 0] = s1[g][e];
+            red[(prow * BN + sg * 8 + e) * 2 + 1] = s2[g][e];
           }
         }
         __syncthreads();
-        const int m0r = r * RPX;
-        const int n = img0 + m0r / (p.TH * p.TW);
+        const int n = img0 + ((g * RG) >> p.thw_shift);
         if (tid < BN && nb * BN + tid < p.Cout && n < p.N) {
           float t1 = 0.f, t2 = 0.f;
           for (int q = 0; q < PR; ++q) { t1 += red[(q * BN + tid) * 2]; t2 += red[(q * BN + tid) * 2 + 1]; }
-          // slab of this round inside its image: (tile of the image) * WM + r for one-image tiles, 0 otherwise
-          const int slab = p.TI == 1 ? (mt % (p.tiles_x * p.tiles_y)) * WM + r : 0;
+          // slab of this group inside its image: (tile of the image) * SGROUPS + g for one-image tiles
+          const int slab = p.TI == 1 ? (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g : 0;
           float* dst = p.stats + (((long long)n * p.stat_slabs + slab) * p.Cout + nb * BN + tid) * 2;
           dst[0] = t1;
           dst[1] = t2;
         }
       }
     }
+    ADM_TSTAMP(6);
     return;
   }
   // fp32 NCHW (output head / stem backward): few channels, direct stores
@@ -741,7 +788,7 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
 template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
 int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int BN = WN * TN * 16;
-  constexpr int smem = conv_smem_bytes<64 * WM * WN, BN, HALO, TM * 16>();
+  constexpr int smem = conv_smem_bytes<64 * WM * WN, BN, HALO, WM * TM * 16>();
   static bool attr_set_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -779,6 +826,9 @@ bool conv_geometry(ConvK& k, int BM, int taps, int halo_max) {
   if (k.TI > TI_MAX || k.TI * (k.TH + 2 * pad) * (k.TW + 2 * pad) > halo_max) return false;
   k.tiles_x = k.W / k.TW;
   k.tiles_y = k.H / k.TH;
+  if ((k.TW & (k.TW - 1)) || (k.TH & (k.TH - 1))) return false;
+  k.tw_shift = __builtin_ctz(k.TW);
+  k.thw_shift = __builtin_ctz(k.TH * k.TW);
   return true;
 }
 
@@ -822,17 +872,27 @@ int pick_variant(const adm_conv_args* a) {
   return (w96 * 0.85 <= w64) ? 2 : 4;
 }
 
-// slabs of the fused output statistics: one per (256-pixel tile, wave row) on maps >= 16x16, one per
-// image on 8x8 maps; 0 = not offered for this configuration
+// slabs of the fused output statistics: one per 256-pixel tile on maps >= 16x16, one per image on 8x8
+// maps; 0 = not offered for this configuration
 int stat_slabs_for(const adm_conv_args* a, int variant) {
   if (a->out_mode != 0 || variant == 7) return 0;
   const int hw = a->h * a->w;
   if (hw <= 64) return hw == 64 ? 1 : 0;
   if (a->h < 16 || a->w < 16 || hw % 256 != 0) return 0;
-  return (hw / 256) * (variant == 3 ? 4 : 2);
+  return hw / 256;
 }
 
 }  // namespace
+
+#ifdef ADM_CONV_TIMING
+extern "C" int adm_conv_timing_read(unsigned long long* host, int nblocks) {
+  if (nblocks > 16384) nblocks = 16384;
+  void* dptr = nullptr;
+  if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(adm_conv_timing_buf)) != hipSuccess) return -1;
+  if (hipMemcpy(host, dptr, (size_t)nblocks * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (int)hipMemset(dptr, 0, sizeof(unsigned long long) * 16 * 16384);
+}
+#endif
 
 extern "C" int64_t adm_packed_weight_elems(int cout, int cin, int taps) {
   if (cout <= 0 || cin <= 0 || cin % KC != 0 || (taps != 1 && taps != 9)) return -1;

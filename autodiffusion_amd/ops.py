@@ -260,7 +260,8 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
         e0.record()
         check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
         e1.record()
-        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64, a.prologue)))
+        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64, a.prologue),
+                             (n, h, w, c0 + c1, cout)))
         return out
     check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
     return out

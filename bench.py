@@ -82,6 +82,8 @@ def main():
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse N ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--conv-breakdown", action="store_true",
+                    help="print per-shape conv time / TFLOP/s (HIP events) to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,10 +162,18 @@ def main():
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
         # dominant kernel symbol: conv_kernel<2, 4, 8, 3, 2, 9, 324, 2> = fused GN+SiLU prologue, 3x3 conv,
         # 256-pixel x 192-channel tile, 8 waves
+        if args.conv_breakdown and rank == 0:
+            agg = {}
+            for e0, e1, f, key, shape in prof:
+                a = agg.setdefault((key, shape), [0.0, 0.0, 0])
+                a[0] += e0.elapsed_time(e1); a[1] += f; a[2] += 1
+            for (key, shape), (ms_, fl_, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                print(f"conv {key} nhwc_in={shape[:4]} cout={shape[4]} x{cnt // args.steps}: "
+                      f"{ms_ / args.steps:8.2f} ms/batch {fl_ / ms_ / 1e9:7.1f} TFLOP/s", file=sys.stderr)
         dom = [p for p in prof if p[3] == (5, 9, True, 2)]
         if dom:
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in dom)
-            fl = sum(f for _, _, f, _ in dom)
+            ms = sum(p[0].elapsed_time(p[1]) for p in dom)
+            fl = sum(p[2] for p in dom)
             achieved = fl / (ms * 1e-3) / 1e12
             traffic = None
             tp = os.path.join(ROOT, "profiles", "r01", "pmc_dominant_kernel_traffic.json")

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Per-block phase timing of conv_kernel (debug build: `make -C autodiffusion_amd/csrc timing`, then run with
+ADM_HIP_LIB=autodiffusion_amd/libadm_hip_timing.so).  Every block's wave 0 stamps s_memtime at kernel entry,
+after the prologue (first halo chunk parked), after the K loop and after the epilogue; this prints the mean
+of each phase in microseconds (100 MHz constant clock) and how many blocks ran per CU."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from autodiffusion_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda:0"
+VARIANT = int(os.environ.get("VARIANT", "0"))
+SHAPES = [
+    ("192->192 @64 3x3 gn+res", 256, 64, 192, 192, 9, 2, True),
+    ("384->384 @32 3x3 gn+res", 256, 32, 384, 384, 9, 2, True),
+    ("384->384 @32 3x3 raw", 256, 32, 384, 384, 9, 0, False),
+    ("768->768 @8 3x3 gn+res", 256, 8, 768, 768, 9, 2, True),
+    ("qkv 384->1152 @32 1x1", 256, 32, 384, 1152, 1, 1, False),
+    ("proj 384->384 @32 1x1 res", 256, 32, 384, 384, 1, 0, True),
+]
+
+
+def main():
+    lib = _lib.load()
+    fn = lib.adm_conv_timing_read
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for name, n, hw, cin, cout, taps, prologue, res in SHAPES:
+        k = 3 if taps == 9 else 1
+        x0 = torch.randn(n, hw, hw, cin, device=DEV).to(torch.bfloat16)
+        w = torch.randn(cout, cin, k, k, device=DEV) * (cin * taps) ** -0.5
+        wp = ops.pack_conv_weight(w)
+        b = torch.randn(cout, device=DEV) * 0.1
+        aff = (1 + 0.1 * torch.randn(n, cin, device=DEV), 0.1 * torch.randn(n, cin, device=DEV)) if prologue else None
+        r = torch.randn(n, hw, hw, cout, device=DEV).to(torch.bfloat16) if res else None
+        out = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+        for _ in range(3):
+            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+        torch.cuda.synchronize()
+        scratch = np.zeros((16384, 16), dtype=np.uint64)
+        fn(scratch.ctypes.data, 16384)  # clears the device buffer
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        for _ in range(int(os.environ.get("PRE", "0"))):  # sustained load before the stamped launch
+            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+        e0.record()
+        ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+        e1.record()
+        torch.cuda.synchronize()
+        buf = np.zeros((16384, 16), dtype=np.uint64)
+        rc = fn(buf.ctypes.data, 16384)
+        assert rc == 0, rc
+        buf = buf[buf[:, 6] > 0]
+        t = buf[:, :7].astype(np.int64)
+        kern_us = e0.elapsed_time(e1) * 1e3
+        tick = 100.0  # s_memrealtime: 100 MHz
+        span = (t[:, 6].max() - t[:, 0].min()) / tick
+        d = np.diff(t, axis=1) / tick
+        hw_id, xcc = buf[:, 14].astype(np.int64), buf[:, 15].astype(np.int64) & 0xF
+        cu = (xcc << 8) | (((hw_id >> 13) & 7) << 5) | (((hw_id >> 12) & 1) << 4) | ((hw_id >> 8) & 0xF)
+        ncu = len(np.unique(cu))
+        names = ["prologue", "k-loop", "epi:wait", "epi:stage0", "epi:sweep0", "epi:rest"]
+        tot = (t[:, 6] - t[:, 0]) / tick
+        print(f"{name:28s} kernel {kern_us:8.1f} us | {len(buf)} blocks on {ncu} CUs | span {span:8.1f} us | block {tot.mean():7.2f} us "
+              f"(sum/CU {tot.sum() / ncu:8.1f}) | "
+              + "  ".join(f"{nm} {d[:, i].mean():6.2f}" for i, nm in enumerate(names)))
+
+
+if __name__ == "__main__":
+    main()
