@@ -15,13 +15,21 @@
 //                output channels of one pixel (8-byte bf16 stores into the NHWC row)
 //
 // Work decomposition
-//   block tile  BM = 256 pixels (a TH x TW patch of TI images) x BN output channels, 4 waves
+//   block tile  BM = 256 pixels (a TH x TW patch of one image; 128 pixels = two 8x8 images on the smallest
+//               maps) x BN = 192 or 128 output channels, 8 waves (2 pixel rows x 4 channel columns of
+//               waves, each 8 x {3,2} MFMA tiles of 16x16); the older 4-wave tilings serve odd widths
 //   K loop      over 32-channel chunks of the input; per chunk the (TH+2)x(TW+2) halo patch is
 //               fetched ONCE from HBM/L2 (register-staged, 16 B per lane), the per-(image,channel)
 //               affine + SiLU is applied in fp32, the result is rounded to bf16 and parked in LDS
-//               (96-byte pixel rows: conflict-free ds_read_b128 for the 16-pixel fragment), and
-//               then reused by all 9 taps; zero padding is applied after the activation
-//   weights     one [BN x 32] tile per (chunk, tap), double-buffered in LDS, prefetched a step ahead
+//               (96-byte pixel rows: conflict-free ds_read_b128 for the 16-pixel fragment), double
+//               buffered, and then reused by all 9 taps; zero padding is applied after the activation
+//   weights     fragment-ordered in HBM/L2, so each wave loads its own fragments straight into registers
+//               (ring of 3 K-steps for 3x3, 4 for 1x1): no LDS, no per-tap barrier
+//   epilogue    accumulators (started from the bias) -> bf16 -> LDS (whole tile) -> coalesced 16-byte row
+//               stores with the residual added on the way and the output's GroupNorm partial sums
+//               (sum, sum of squares per channel) reduced per tile, for the consumer's GroupNorm
+//   launch      persistent: one block per CU slot walks an XCD-aware list of tiles and starts the next
+//               tile's first chunk by LDS-DMA while the finished tile is stored (see conv_kernel)
 #include <stdlib.h>
 
 #include <type_traits>
@@ -45,8 +53,10 @@ struct ConvK {
   int N, H, W, C0, C1, Cout;
   int TH, TW, TI, tiles_x, tiles_y;
   int tw_shift, thw_shift;   // log2(TW), log2(TH*TW)
+  unsigned rcp_hpi, rcp_hw2; // ceil(2^20 / halo pixels per image), ceil(2^20 / halo row width): x / d == (x * rcp) >> 20 for x < 512
   int out_mode;
   int ntiles16, nblocks_n;
+  int total_tiles;           // pixel tiles x Cout blocks (persistent launch: blocks walk this list)
   unsigned wbytes;
 };
 
@@ -68,21 +78,35 @@ constexpr int conv_smem_bytes() {
   return (k > e ? k : e) > r ? (k > e ? k : e) : r;
 }
 
+// LDS map of conv_kernel: halo[0] | halo[1] ... | affine tables.  The epilogue's output staging (whole tile,
+// bf16 rows + 16 B pad) and the statistics reduction overlay halo[1] onwards, never halo[0] or the affine
+// tables: those receive the NEXT tile's first chunk while the current tile is being stored.
+template <int NT, int BN, int HALO, int BM>
+struct ConvLds {
+  static constexpr int HB = halo_slots<NT, HALO>() * ROWB;   // one halo buffer
+  static constexpr int STG = BM * (BN * 2 + 16);             // output staging
+  static constexpr int RED = NT * 64;                        // statistics reduction [NT*8/BN rows][BN][2] floats
+  static constexpr int OVL = (STG > RED ? STG : RED) > HB ? (STG > RED ? STG : RED) : HB;
+  static constexpr int ABUF = (HB + OVL + 15) & ~15;
+  static constexpr int BYTES = ABUF + 2 * TI_MAX * 64 * 4;
+};
+
 #ifdef ADM_CONV_TIMING
 // debug build only (make timing): per-block phase time stamps of conv_kernel, read by tools/conv_timing.py
 __device__ unsigned long long adm_conv_timing_buf[16 * 16384];
-#define ADM_TSTAMP(k)                                                                         \
-  do {                                                                                        \
-    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                             \
-      adm_conv_timing_buf[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();               \
-      if ((k) == 0) {                                                                         \
-        adm_conv_timing_buf[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  \
-        adm_conv_timing_buf[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_getreg((31 << 11) | 20); \
-      }                                                                                       \
-    }                                                                                         \
+#define ADM_TSTAMP(tile, k)                                                                             \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && (tile) < 16384) {                                                           \
+      adm_conv_timing_buf[(tile) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                        \
+      if ((k) == 1 || (k) == 2) adm_conv_timing_buf[(tile) * 16 + 7 + (k)] = __builtin_amdgcn_s_memtime(); \
+      if ((k) == 0) {                                                                                   \
+        adm_conv_timing_buf[(tile) * 16 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);              \
+        adm_conv_timing_buf[(tile) * 16 + 15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);             \
+      }                                                                                                 \
+    }                                                                                                   \
   } while (0)
 #else
-#define ADM_TSTAMP(k) do {} while (0)
+#define ADM_TSTAMP(tile, k) do {} while (0)
 #endif
 
 __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -94,21 +118,29 @@ __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned vo
 // PRO = prologue (0 raw, 1 affine, 2 affine + SiLU).  Everything the inner loop branches on is a
 // template parameter: a K-step is one straight-line block (1 halo load, 1 halo transform + LDS write,
 // TN weight loads, TM LDS reads, TM*TN MFMAs) that the scheduler can software-pipeline.
+//
+// The launch is PERSISTENT: one block per CU slot walks a static, XCD-aware list of output tiles.  A block
+// of the 8-wave tilings is alone on its CU (> 128 VGPRs per wave), so nothing else would hide a tile's
+// prologue (descriptor / index setup, first halo chunk, affine tables, first weight fragments: 3-4 us of
+// dependent latencies) or the block launch gap; here the NEXT tile's first loads are issued before the
+// current tile's accumulators are staged and stored, and land in LDS (halo buffer 0, which the output
+// staging does not overlay) while the epilogue runs.
 template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 conv_kernel(const ConvK p) {
   constexpr int NT = 64 * WM * WN;
+  constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
   constexpr int PASSES = (HALO * 4 + NT - 1) / NT;
-  constexpr int HSLOT = halo_slots<NT, HALO>();
   constexpr int PAD = TAPS == 9 ? 1 : 0;
-  constexpr int SGROUPS = stat_groups<WM * TM * 16>();  // statistics slabs per tile
+  constexpr int SGROUPS = stat_groups<BM>();  // statistics slabs per tile
+  using Lds = ConvLds<NT, BN, HALO, BM>;
   static_assert(TAPS == 1 || PASSES <= TAPS - 1, "halo passes must fit in the taps of one chunk");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const halo = smem;                       // [2][HSLOT * ROWB]
-  float* const abuf = reinterpret_cast<float*>(smem + 2 * HSLOT * ROWB);
-  ADM_TSTAMP(0);
+  unsigned char* const halo = smem;               // [2][Lds::HB]
+  unsigned char* const stg = smem + Lds::HB;      // output staging / statistics reduction: overlays halo[1]
+  float* const abuf = reinterpret_cast<float*>(smem + Lds::ABUF);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,55 +148,33 @@ conv_kernel(const ConvK p) {
   const int wm = wave / WN, wn = wave % WN;
   const int lc = lane & 15, lq = lane >> 4;
 
-  // XCD-aware tile order: the dispatcher deals consecutive blocks round-robin to the 8 XCDs (each with its own
-  // L2), so block b runs logical tile (b % 8) * ceil-share + b / 8: one XCD then owns a contiguous run of
-  // tiles -- all Cout blocks of a pixel tile and its spatial neighbours (shared halo rows) hit the same L2
-  const unsigned tshare = gridDim.x >> 3, trem = gridDim.x & 7, xcd = blockIdx.x & 7;
-  const int ltile = (int)(xcd * tshare + min(xcd, trem) + (blockIdx.x >> 3));
-  const int nb = ltile % p.nblocks_n;
-  const int mt = ltile / p.nblocks_n;
+  // XCD-aware static tile list: the dispatcher deals consecutive blocks round-robin to the 8 XCDs (each with
+  // its own L2); XCD x owns the contiguous run [tstart, tstart + tcount) of logical tiles and its gx blocks
+  // take them interleaved, so the tiles in flight on one L2 are neighbours: all Cout blocks of a pixel tile
+  // and the adjacent pixel tiles (shared halo rows)
+  const int xcd = blockIdx.x & 7;
+  const int gx = (int)(gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7));
+  const int tcount = (p.total_tiles >> 3) + (xcd < (p.total_tiles & 7));
+  const int tstart = xcd * (p.total_tiles >> 3) + min(xcd, p.total_tiles & 7);
+  int tl = blockIdx.x >> 3;
+  if (tl >= tcount) return;
+
   const int HW2 = p.TW + 2 * PAD;
   const int HPI = (p.TH + 2 * PAD) * HW2;
   const int HP = p.TI * HPI;
   const int Cin = p.C0 + p.C1;
   const int HWimg = p.H * p.W;
-
-  int img0, y0, x0;
-  if (p.TI == 1) {
-    const int per_img = p.tiles_x * p.tiles_y;
-    img0 = mt / per_img;
-    const int r = mt % per_img;
-    y0 = (r / p.tiles_x) * p.TH;
-    x0 = (r % p.tiles_x) * p.TW;
-  } else {
-    img0 = mt * p.TI;
-    y0 = 0;
-    x0 = 0;
-  }
-  const int nimg = min(p.TI, p.N - img0);  // images of this tile that exist
-
-  // buffer descriptors over exactly the images this tile may touch: anything else reads as zero
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in0 + (long long)img0 * HWimg * p.C0), 0, nimg * HWimg * p.C0 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.C1 ? p.in1 + (long long)img0 * HWimg * p.C1 : p.in0), 0, p.C1 ? nimg * HWimg * p.C1 * 2 : 0, 0x00020000);
+  const int chunks = Cin / KC;
+  const int c0chunks = p.C0 / KC;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.Cout * 4, 0x00020000);
 
   // ---- halo staging geometry: 16-byte segment s = tid + pass*NT -> (halo pixel s>>2, segment s&3)
-  int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch / spare slot)
   unsigned ti_pack = 0;    // image-in-tile of each pass, 4 bits each
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
-    const int s = tid + ps * NT;
-    const int hp = s >> 2;
-    int off = -1;
-    if (hp < HP) {
-      const int ti = hp / HPI, rem = hp % HPI;
-      const int y = y0 + rem / HW2 - PAD, x = x0 + rem % HW2 - PAD;
-      if (ti < nimg && y >= 0 && y < p.H && x >= 0 && x < p.W) off = (ti * p.H + y) * p.W + x;
-      ti_pack |= (unsigned)ti << (4 * ps);
-    }
-    pixrel[ps] = off;
+    const int hp = (tid + ps * NT) >> 2;
+    if (hp < HP) ti_pack |= (unsigned)(hp / HPI) << (4 * ps);
   }
   const int seg = tid & 3;  // NT % 4 == 0 -> the same channel segment in every pass
   const int hslot = (tid >> 2) * ROWB + seg * 16;  // LDS byte offset of pass 0's slot; pass ps adds ps*(NT/4)*ROWB
@@ -180,24 +190,81 @@ conv_kernel(const ConvK p) {
     const int ti = m0 / (p.TH * p.TW), rem = m0 % (p.TH * p.TW);
     aoff[i] = (ti * HPI + (rem / p.TW) * HW2) * ROWB;
   }
+  const unsigned wstep = (unsigned)p.ntiles16 * 1024u;  // bytes per K-step
+
+  // ---- per-tile state (rewritten at every tile switch)
+  int nb = 0, mt = 0, img0 = 0, y0 = 0, x0 = 0;
+  __amdgpu_buffer_rsrc_t rs0 = rsw, rs1 = rsw;
+  int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch / spare slot)
   // weight fragments go straight from the packed image (L2-resident, fragment-ordered: one 1 KB
   // coalesced run per wave-load) into registers -- no LDS, no per-tap barrier
   unsigned wofs[TN];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  // scalar part: tile -> Cout block, pixel-tile index, first image, origin
+  auto tile_origin = [&](int lt, int& nb_, int& mt_, int& img0_, int& y0_, int& x0_) {
+    nb_ = lt % p.nblocks_n;
+    mt_ = lt / p.nblocks_n;
+    if (p.TI == 1) {
+      const int per_img = p.tiles_x * p.tiles_y;
+      img0_ = mt_ / per_img;
+      const int r = mt_ % per_img;
+      y0_ = (r / p.tiles_x) * p.TH;
+      x0_ = (r % p.tiles_x) * p.TW;
+    } else {
+      img0_ = mt_ * p.TI;
+      y0_ = 0;
+      x0_ = 0;
+    }
+  };
+  // per-lane part, from (nb, img0, y0, x0)
+  auto tile_setup = [&]() {
+    const int nimg = min(p.TI, p.N - img0);  // images of this tile that exist
+    // buffer descriptors over exactly the images this tile may touch: anything else reads as zero
+    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (long long)img0 * HWimg * p.C0), 0, nimg * HWimg * p.C0 * 2, 0x00020000);
+    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C1 ? p.in1 + (long long)img0 * HWimg * p.C1 : p.in0), 0,
+                                            p.C1 ? nimg * HWimg * p.C1 * 2 : 0, 0x00020000);
+    // the halo pixel of each pass is recomputed per tile from an opaque copy of the thread index: nothing
+    // per-lane has to survive the K loop (it runs at the VGPR cap; a reload from scratch costs a dependent
+    // memory round trip here).  Divisions by the patch size / width are multiplications by host-made
+    // reciprocals (exact for hp < 512), and the tests are evaluated without branches.
+    int tid_s = tid;
+    asm volatile("" : "+v"(tid_s));
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int tile = nb * (BN / 16) + wn * TN + j;
-    wofs[j] = tile < p.ntiles16 ? (unsigned)((tile * 64 + lane) * 16) : OOB;
-  }
-  const unsigned wstep = (unsigned)p.ntiles16 * 1024u;  // bytes per K-step
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int hp = (tid_s + ps * NT) >> 2;
+      const int ti = (int)(((unsigned)hp * p.rcp_hpi) >> 20), rem = hp - ti * HPI;
+      const int ry = (int)(((unsigned)rem * p.rcp_hw2) >> 20), rx = rem - ry * HW2;
+      const int y = y0 + ry - PAD, x = x0 + rx - PAD;
+      const int ok = (int)(hp < HP) & (int)(ti < nimg) & (int)(y >= 0) & (int)(y < p.H) & (int)(x >= 0) & (int)(x < p.W);
+      pixrel[ps] = ok ? (ti * p.H + y) * p.W + x : -1;
+    }
+    // LDS-DMA of the tile's first chunk (see first_park): raw halo chunk 0, lane-linear into halo[0] ...
+    const int seg_s = tid_s & 3, lane_s = tid_s & 63;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * p.C0 + seg_s * 8) * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(halo + (ps * NT + wave * 64) * 16), 16, (int)voff, 0, 0, 0);
+    }
+    // ... and the affine tables of chunks 0 and 1 (they are staged two chunks ahead): the LDS table is
+    // a[buf][ti][32] followed by b[buf][ti][32], so ONE wave-instruction moves each half: wave 0 the a half,
+    // wave 1 the b half, lane = buf*32 + ti*8 + part -> 4 floats from row n of chunk buf (32-bit offsets
+    // into a descriptor over the whole [N][Cin] table)
+    if constexpr (PRO != 0) {
+      if (wave < 2) {
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(wave == 0 ? p.aa : p.ab), 0, p.N * Cin * 4, 0x00020000);
+        const int ti = (lane_s >> 3) & 3, n = min(img0 + ti, p.N - 1);
+        const unsigned voff = ti < p.TI ? (unsigned)(n * Cin + min(lane_s >> 5, chunks - 1) * KC + (lane_s & 7) * 4) * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(abuf + wave * (2 * TI_MAX * 32)), 16, (int)voff, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int tile = nb * (BN / 16) + wn * TN + j;
+      wofs[j] = tile < p.ntiles16 ? (unsigned)((tile * 64 + lane) * 16) : OOB;
+    }
+  };
 
   f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int chunks = Cin / KC;
-  const int c0chunks = p.C0 / KC;
 
   // activation segment `ps` of chunk c (the descriptor select is scalar; out-of-image lanes read zero)
   auto halo_load = [&](int c, int ps) -> uint4 {
@@ -207,27 +274,33 @@ conv_kernel(const ConvK p) {
     const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
     return bufload16(rs, voff, 0);
   };
-  auto stage_affine = [&](int c, int buf) {
+  // affine table of chunk c: threads < TI*16 fetch one float4 of a (parts 0-7) or b (parts 8-15)
+  auto affine_load = [&](int c, int im0) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PRO != 0) {
       if (tid < p.TI * 16) {
-        const int ti = tid >> 4, part = tid & 15;
-        const int n = min(img0 + ti, p.N - 1);
-        const float* s = (part < 8 ? p.aa : p.ab) + (long long)n * Cin + c * KC + (part & 7) * 4;
-        *reinterpret_cast<float4*>(abuf + (buf * TI_MAX + ti) * 64 + (part < 8 ? 0 : 32) + (part & 7) * 4) =
-            *reinterpret_cast<const float4*>(s);
+        const int n = min(im0 + (tid >> 4), p.N - 1);
+        v = *reinterpret_cast<const float4*>(((tid & 15) < 8 ? p.aa : p.ab) + (long long)n * Cin + c * KC + (tid & 7) * 4);
       }
+    }
+    return v;
+  };
+  auto affine_park = [&](float4 v, int buf) {
+    if constexpr (PRO != 0) {
+      if (tid < p.TI * 16)
+        *reinterpret_cast<float4*>(abuf + ((tid & 15) < 8 ? 0 : 2 * TI_MAX * 32) + (buf * TI_MAX + (tid >> 4)) * 32 + (tid & 7) * 4) = v;
     }
   };
   // transform (fp32 affine [+ SiLU], rounded to bf16) and park a segment; zero padding stays exactly zero
   auto halo_write = [&](uint4 v, int ps, int buf) {
     if constexpr (PRO != 0) {
       const int ti = (ti_pack >> (4 * ps)) & 15;
-      const float* ab = abuf + (buf * TI_MAX + ti) * 64 + seg * 8;
+      const float* ab = abuf + (buf * TI_MAX + ti) * 32 + seg * 8;
       float a8[8], b8[8];
       *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ab);
       *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ab + 4);
-      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 32);
-      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 36);
+      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * 32);
+      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * 32 + 4);
       uint32_t u[4] = {v.x, v.y, v.z, v.w};
       const bool valid = pixrel[ps] >= 0;
 #pragma unroll
@@ -241,7 +314,7 @@ conv_kernel(const ConvK p) {
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
     }
-    *reinterpret_cast<uint4*>(halo + buf * (HSLOT * ROWB) + ps * (NT / 4) * ROWB + hslot) = v;
+    *reinterpret_cast<uint4*>(halo + buf * Lds::HB + ps * (NT / 4) * ROWB + hslot) = v;
   };
   auto load_w = [&](int step, uint4 (&dst)[TN]) {
 #pragma unroll
@@ -276,227 +349,302 @@ conv_kernel(const ConvK p) {
     }
   };
 
-  // ---- prologue: chunk 0 halo; the affine tables of chunks 0 and 1 (they are staged two chunks ahead)
-  stage_affine(0, 0);
-  if (chunks > 1) stage_affine(1, 1);
-  {
-    uint4 h0[PASSES];
+  // ---- a tile's first loads.  The K loop already runs at the 256-VGPR cap, so nothing wide can be held
+  // in registers across it or across the staging of the accumulators: the next tile's first halo chunk (raw
+  // bf16) and its first two affine tables go global -> LDS by LDS-DMA (buffer_load ... lds / global_load_lds:
+  // no VGPR destination) as soon as the K loop has released halo[0] and the affine tables, and land while the
+  // accumulators are staged.  The raw chunk is lane-linear in halo[0] (segment s at byte 16 s); first_park
+  // reads it back, and after a barrier writes the transformed segments to their padded pixel rows.
+  // The narrow register loads (first weight fragments: 3x3 ring of 3 K-steps, two in flight; 1x1 ring of
+  // 4, three in flight, plus the activation segments of chunk 1; the bias fragment the accumulators start
+  // from) go out once the accumulators' registers are free.
+  constexpr int WRING = TAPS == 9 ? 3 : 4;
+  uint4 wr[WRING][TN];
+  uint4 ring[2][PASSES];
+  float4 bs[TN];
+  const int last = chunks - 1;
+  auto first_loads = [&](int lq_) {
+    load_w(0, wr[0]);
+    load_w(min(1, TAPS == 9 ? 9 * chunks - 1 : last), wr[1]);
+    if constexpr (TAPS == 1) {
+      load_w(min(2, last), wr[2]);
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) h0[ps] = halo_load(0, ps);
-    __syncthreads();  // abuf[0] visible
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) halo_write(h0[ps], ps, 0);
-  }
-  ADM_TSTAMP(1);
-
-  if constexpr (TAPS == 9) {
-    // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
-    uint4 wreg[3][TN];
-    load_w(0, wreg[0]);
-    load_w(1, wreg[1]);
-    __syncthreads();
-    auto chunk = [&](int c, auto more_) {
-      constexpr bool MORE = decltype(more_)::value;
-      const int hb = c & 1;
-      const int step0 = c * 9;
-      uint4 hprev = make_uint4(0, 0, 0, 0);
-      float4 affv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        // next chunk's halo: pass t is fetched now; pass t-1 (fetched during the previous tap) is
-        // transformed and parked in the other halo buffer
-        uint4 hcur = make_uint4(0, 0, 0, 0);
-        if constexpr (MORE) {
-          if (t < PASSES) hcur = halo_load(c + 1, t);
-        }
-        if (MORE || t + 2 < 9) load_w(step0 + t + 2, wreg[(t + 2) % 3]);
-        // small maps (128-pixel tiles): a mid-chunk rendezvous keeps the waves that share weight fragments
-        // in step (L1 reuse); on the 256-pixel tiles it only cost time and is omitted
-        if (HALO <= 200 && t == 1) __syncthreads();
-        if constexpr (MORE && PRO != 0) {
-          // affine table of chunk c+2 -> abuf[hb] (its readers, chunk c-1's transforms, are behind the last
-          // barrier): fetched at tap 0, parked at tap 7 so that no wave ever waits on that load
-          if (t == 0 && c + 2 < chunks && tid < p.TI * 16) {
-            const int n = min(img0 + (tid >> 4), p.N - 1);
-            affv = *reinterpret_cast<const float4*>(((tid & 15) < 8 ? p.aa : p.ab) + (long long)n * Cin + (c + 2) * KC + (tid & 7) * 4);
-          }
-          if (t == 7 && c + 2 < chunks && tid < p.TI * 16)
-            *reinterpret_cast<float4*>(abuf + (hb * TI_MAX + (tid >> 4)) * 64 + ((tid & 15) < 8 ? 0 : 32) + (tid & 7) * 4) = affv;
-        }
-        if constexpr (MORE) {
-          if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
-        }
-        hprev = hcur;
-        mfma_tap(halo + hb * (HSLOT * ROWB) + ((t / 3) * HW2 + (t % 3)) * ROWB, wreg[t % 3]);
-      }
-      __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
-    };
-    for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
-    chunk(chunks - 1, std::false_type{});
-  } else {
-    // 1x1: one K-step (TM*TN MFMAs per wave) per chunk, so HBM/L2 latency must be covered by depth, not
-    // by the taps: activation segments are fetched 2 chunks ahead (register ring of 2), weight fragments
-    // 3 chunks ahead (ring of 4); one barrier per chunk.  The loop is unrolled by 4 so that every ring
-    // slot is a compile-time register; indices past the last chunk are clamped (harmless re-reads).
-    uint4 ring[2][PASSES];
-    uint4 wq[4][TN];
-    const int last = chunks - 1;
-    load_w(0, wq[0]);
-    load_w(min(1, last), wq[1]);
-    load_w(min(2, last), wq[2]);
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(1, last), ps);
-    __syncthreads();
-    auto body = [&](int c, auto sa_, auto sw_) {
-      constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
-      if (c > last) return;
-      const int c2 = min(c + 2, last);
-      stage_affine(c2, c & 1);
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
-      load_w(min(c + 3, last), wq[(SW + 3) % 4]);
-      mfma_tap(halo + (c & 1) * (HSLOT * ROWB), wq[SW]);
-#pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
-      __syncthreads();
-    };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    for (int c0 = 0; c0 < chunks; c0 += 4) {
-      body(c0, I0{}, I0{});
-      body(c0 + 1, I1{}, I1{});
-      body(c0 + 2, I0{}, I2{});
-      body(c0 + 3, I1{}, I3{});
+      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(1, last), ps);
     }
-  }
-
-  ADM_TSTAMP(2);
-  // ---- epilogue: lane (lc, lq) holds channels 4*lq..4*lq+3 of tile j for pixel lc of tile i
-  if (p.out_mode == 0) {
-    // bf16 NHWC.  The block is alone on its CU (8 waves x > 128 VGPRs), so nothing else hides this phase:
-    // the whole tile (acc + bias, bf16) is staged in LDS in ONE round and leaves as whole pixel rows with
-    // 16-byte lanes (BN*2 contiguous bytes per pixel); the residual operand is fetched with the same
-    // coalesced shape BEFORE the staging barrier, so that its latency overlaps the LDS round trip.
-    // (Fragment-shaped 8-byte stores touch 16 cache lines per instruction and dominated 1x1 convs.)
-    constexpr int BM = WM * TM * 16;
-    constexpr int EROW = BN * 2 + 16;       // staged bytes per pixel
-    constexpr int SEGS = BN / 8;            // 16-byte segments per pixel
-    constexpr int PR = NT / SEGS;           // pixel rows written per sweep
-    constexpr int RG = BM / SGROUPS;        // pixel rows per statistics group
-    constexpr int NIT = (RG + PR - 1) / PR; // sweeps per group
-    uint16_t* const outp = reinterpret_cast<uint16_t*>(p.out);
-    // each thread keeps ONE 16-byte channel segment and walks pixel rows, so that it can also accumulate
-    // the GroupNorm statistics of the values it stores (the consumer's adm_gn_partial pass is then unnecessary)
-    const int sg = tid % SEGS, prow = tid / SEGS;
-    const int gch = nb * BN + sg * 8;
-    const bool act = prow < PR && gch < p.Cout;
-    const int thw_mask = (1 << p.thw_shift) - 1, tw_mask = (1 << p.tw_shift) - 1;
-    long long eoff[SGROUPS][NIT];           // element offset of the thread's segment in out / res, or -1
-    uint4 rr[SGROUPS][NIT];
-#pragma unroll
-    for (int g = 0; g < SGROUPS; ++g)
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int ml = prow + k * PR, m = g * RG + ml;
-        const int ti = m >> p.thw_shift, rem = m & thw_mask;
-        const int n = img0 + ti;
-        const long long pix = ((long long)n * p.H + y0 + (rem >> p.tw_shift)) * p.W + x0 + (rem & tw_mask);
-        eoff[g][k] = (act && ml < RG && n < p.N) ? pix * p.Cout + gch : -1;
-        rr[g][k] = make_uint4(0, 0, 0, 0);
-        if (p.res && eoff[g][k] >= 0) rr[g][k] = *reinterpret_cast<const uint4*>(p.res + eoff[g][k]);
-      }
-    __syncthreads();  // every wave is done with the halo buffers
-    ADM_TSTAMP(3);
+    // bias fragment (whole float4 or nothing: a ragged last fragment only exists with the fp32 NCHW output,
+    // which adds those channels' bias at the store)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int ch0 = (wn * TN + j) * 16 + lq * 4;
-      const int bch = nb * BN + ch0;
-      float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bch + 3 < p.Cout) bs = *reinterpret_cast<const float4*>(p.bias + bch);
+      const int bch = nb * BN + (wn * TN + j) * 16 + lq_ * 4;
+      const uint4 b = bufload16(rsb, bch + 3 < p.Cout ? (unsigned)bch * 4u : OOB, 0);
+      bs[j] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+    }
+  };
+  auto first_park = [&]() {  // after a barrier behind the DMA: raw chunk and affine tables visible
+    uint4 raw[PASSES];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        uint2 o;
-        o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0] + bs.x) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1] + bs.y) << 16);
-        o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2] + bs.z) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3] + bs.w) << 16);
-        *reinterpret_cast<uint2*>(smem + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
+    for (int ps = 0; ps < PASSES; ++ps) raw[ps] = *reinterpret_cast<const uint4*>(halo + (ps * NT + tid) * 16);
+    __syncthreads();  // every raw segment is in registers: the padded rows may overwrite the linear image
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) halo_write(raw[ps], ps, 0);
+  };
+
+  int ltile = tstart + tl;
+  tile_origin(ltile, nb, mt, img0, y0, x0);
+  tile_setup();
+  first_loads(lq);
+  __syncthreads();
+  first_park();
+
+  for (;;) {
+    ADM_TSTAMP(ltile, 0);
+    // the accumulators start from the bias (fp32), so the epilogue has no bias operand to wait for
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{bs[j].x, bs[j].y, bs[j].z, bs[j].w};
+    __syncthreads();  // halo[0] complete; the previous tile's staging / reduction reads are done
+    ADM_TSTAMP(ltile, 1);
+
+    const int tnext = tl + gx;
+    const bool more = tnext < tcount;
+    if constexpr (TAPS == 9) {
+      // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
+      auto chunk = [&](int c, auto more_) {
+        constexpr bool MORE = decltype(more_)::value;
+        const int hb = c & 1;
+        const int step0 = c * 9;
+        uint4 hprev = make_uint4(0, 0, 0, 0);
+        float4 affv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          // next chunk's halo: pass t is fetched now; pass t-1 (fetched during the previous tap) is
+          // transformed and parked in the other halo buffer
+          uint4 hcur = make_uint4(0, 0, 0, 0);
+          if constexpr (MORE) {
+            if (t < PASSES) hcur = halo_load(c + 1, t);
+          }
+          if (MORE || t + 2 < 9) load_w(step0 + t + 2, wr[(t + 2) % 3]);
+          // small maps (128-pixel tiles): a mid-chunk rendezvous keeps the waves that share weight fragments
+          // in step (L1 reuse); on the 256-pixel tiles it only cost time and is omitted
+          if (HALO <= 200 && t == 1) __syncthreads();
+          if constexpr (MORE && PRO != 0) {
+            // affine table of chunk c+2 -> abuf[hb] (its readers, chunk c-1's transforms, are behind the last
+            // barrier): fetched at tap 0, parked at tap 7 so that no wave ever waits on that load
+            if (t == 0 && c + 2 < chunks) affv = affine_load(c + 2, img0);
+            if (t == 7 && c + 2 < chunks) affine_park(affv, hb);
+          }
+          if constexpr (MORE) {
+            if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
+          }
+          hprev = hcur;
+          mfma_tap(halo + hb * Lds::HB + ((t / 3) * HW2 + (t % 3)) * ROWB, wr[t % 3]);
+        }
+        __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
+      };
+      for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
+      chunk(chunks - 1, std::false_type{});
+    } else {
+      // 1x1: one K-step (TM*TN MFMAs per wave) per chunk, so HBM/L2 latency must be covered by depth, not
+      // by the taps: activation segments are fetched 2 chunks ahead (register ring of 2), weight fragments
+      // 3 chunks ahead (ring of 4); one barrier per chunk.  The loop is unrolled by 4 so that every ring
+      // slot is a compile-time register; indices past the last chunk are clamped (harmless re-reads).
+      auto body = [&](int c, auto sa_, auto sw_) {
+        constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
+        if (c > last) return;
+        const int c2 = min(c + 2, last);
+        affine_park(affine_load(c2, img0), c & 1);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
+        load_w(min(c + 3, last), wr[(SW + 3) % 4]);
+        mfma_tap(halo + (c & 1) * Lds::HB, wr[SW]);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
+        __syncthreads();
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      for (int c0 = 0; c0 < chunks; c0 += 4) {
+        body(c0, I0{}, I0{});
+        body(c0 + 1, I1{}, I1{});
+        body(c0 + 2, I0{}, I2{});
+        body(c0 + 3, I1{}, I3{});
       }
     }
-    __syncthreads();
-    ADM_TSTAMP(4);
-    float s1[SGROUPS][8] = {}, s2[SGROUPS][8] = {};
-#pragma unroll
-    for (int g = 0; g < SGROUPS; ++g)
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        if (eoff[g][k] < 0) continue;
-        const int m = g * RG + prow + k * PR;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + m * EROW + sg * 16);
-        uint32_t a4[4] = {v.x, v.y, v.z, v.w};
-        if (p.res) {
-          const uint32_t r4[4] = {rr[g][k].x, rr[g][k].y, rr[g][k].z, rr[g][k].w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
-            const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
-            a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
-          }
-          v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
-        }
-        *reinterpret_cast<uint4*>(outp + eoff[g][k]) = v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float lo = __uint_as_float(a4[q] << 16), hi = __uint_as_float(a4[q] & 0xffff0000u);
-          s1[g][2 * q] += lo; s2[g][2 * q] += lo * lo;
-          s1[g][2 * q + 1] += hi; s2[g][2 * q + 1] += hi * hi;
-        }
-      }
-    ADM_TSTAMP(5);
-    if (p.stats) {
-      // reduce the PR row-partials of every channel through LDS (fixed order: bitwise reproducible)
-      float* red = reinterpret_cast<float*>(smem);  // [PR][BN][2]
+    ADM_TSTAMP(ltile, 2);
+
+    // ---- tile switch.  Every wave is behind the K loop's last barrier: both halo buffers and abuf are free.
+    const int ltile_done = ltile;
+    (void)ltile_done;
+    if (p.out_mode == 0) {
+      // bf16 NHWC: the whole tile (acc + bias, bf16) is staged in LDS in ONE round and leaves as whole pixel
+      // rows with 16-byte lanes (BN*2 contiguous bytes per pixel); the residual operand is fetched with the
+      // same coalesced shape before the staging barrier, so that its latency overlaps the LDS round trip.
+      // (Fragment-shaped 8-byte stores touch 16 cache lines per instruction and dominated 1x1 convs.)
+      constexpr int EROW = BN * 2 + 16;       // staged bytes per pixel
+      constexpr int SEGS = BN / 8;            // 16-byte segments per pixel
+      constexpr int PR = NT / SEGS;           // pixel rows written per sweep
+      constexpr int RG = BM / SGROUPS;        // pixel rows per statistics group
+      constexpr int NIT = (RG + PR - 1) / PR; // sweeps per group
+      // each thread keeps ONE 16-byte channel segment and walks pixel rows, so that it can also accumulate
+      // the GroupNorm statistics of the values it stores (the consumer's adm_gn_partial pass is then unnecessary)
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));  // opaque per tile: keeps this cold address math out of the K loop's live set
+      const int sg = tid_e % SEGS, prow = tid_e / SEGS;
+      const int gch = nb * BN + sg * 8;
+      const bool act = prow < PR && gch < p.Cout;
+      const int thw_mask = (1 << p.thw_shift) - 1, tw_mask = (1 << p.tw_shift) - 1;
+      // (a) this tile's output / residual bases and statistics destinations (the per-row offsets follow the
+      // tile switch: they only need the first image of the finished tile)
+      const long long ebase = (((long long)img0 * p.H + y0) * p.W + x0) * p.Cout + gch;  // element offset of the tile origin
+      uint16_t* const obase = reinterpret_cast<uint16_t*>(p.out) + ebase;
+      const uint16_t* const rbase = p.res ? p.res + ebase : nullptr;
+      const int img0_d = img0;
+      float* sdst[SGROUPS];
 #pragma unroll
       for (int g = 0; g < SGROUPS; ++g) {
-        __syncthreads();  // staging buffer (or the previous group's partials) fully consumed
-        if (prow < PR) {
+        const int n = img0 + ((g * RG) >> p.thw_shift);
+        // slab of this group inside its image: (tile of the image) * SGROUPS + g for one-image tiles
+        const int slab = p.TI == 1 ? (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g : 0;
+        sdst[g] = (p.stats && tid_e < BN && nb * BN + tid_e < p.Cout && n < p.N)
+                      ? p.stats + (((long long)n * p.stat_slabs + slab) * p.Cout + nb * BN + tid_e) * 2 : nullptr;
+      }
+      ADM_TSTAMP(ltile_done, 10);
+      // (b) stage the accumulators (bias included since the start) as bf16 for the whole tile
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            red[(prow * BN + sg * 8 + e) * 2 + 0] = s1[g][e];
-            red[(prow * BN + sg * 8 + e) * 2 + 1] = s2[g][e];
+      for (int j = 0; j < TN; ++j) {
+        const int ch0 = (wn * TN + j) * 16 + lq * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          uint2 o;
+          o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1]) << 16);
+          o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3]) << 16);
+          *reinterpret_cast<uint2*>(stg + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
+        }
+      }
+      ADM_TSTAMP(ltile_done, 11);
+      // (c) switch the tile state; the next tile's first chunk and affine tables start their way into LDS (after the
+      // staging writes: the compiler orders every later LDS access behind a pending LDS-DMA)
+      if (more) {
+        tl = tnext;
+        ltile = tstart + tl;
+        tile_origin(ltile, nb, mt, img0, y0, x0);
+        tile_setup();
+      }
+      int eoff[SGROUPS][NIT];               // element offset relative to the tile origin, or -1
+#pragma unroll
+      for (int g = 0; g < SGROUPS; ++g)
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int ml = prow + k * PR, m = g * RG + ml;
+          const int ti = m >> p.thw_shift, rem = m & thw_mask;
+          eoff[g][k] = (act && ml < RG && img0_d + ti < p.N) ? ((ti * p.H + (rem >> p.tw_shift)) * p.W + (rem & tw_mask)) * p.Cout : -1;
+        }
+      ADM_TSTAMP(ltile_done, 12);
+      uint4 rr[SGROUPS][NIT];
+      // the residual operand: same coalesced shape as the stores; in flight across the barrier and the parking
+      // of the next tile's first chunk (the accumulators' registers are free from here on)
+#pragma unroll
+      for (int g = 0; g < SGROUPS; ++g)
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          rr[g][k] = make_uint4(0, 0, 0, 0);
+          if (rbase && eoff[g][k] >= 0) rr[g][k] = *reinterpret_cast<const uint4*>(rbase + eoff[g][k]);
+        }
+      if (more) first_loads((tid_e & 63) >> 4);
+      ADM_TSTAMP(ltile_done, 13);
+      __syncthreads();
+      ADM_TSTAMP(ltile_done, 3);
+      if (more) first_park();
+      ADM_TSTAMP(ltile_done, 4);
+      // (d) sweep the staged tile out: residual add, store and statistics
+      // packed fp32 math (v_pk_add_f32 / v_pk_fma_f32): this phase is VALU-bound, not store-bound
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 s1[SGROUPS][4], s2[SGROUPS][4];
+#pragma unroll
+      for (int g = 0; g < SGROUPS; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[g][q] = f32x2{0.f, 0.f}; s2[g][q] = f32x2{0.f, 0.f}; }
+#pragma unroll
+      for (int g = 0; g < SGROUPS; ++g)
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          if (eoff[g][k] < 0) continue;
+          uint4 v = *reinterpret_cast<const uint4*>(stg + (g * RG + prow + k * PR) * EROW + sg * 16);
+          uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+          if (rbase) {
+            const uint32_t r4[4] = {rr[g][k].x, rr[g][k].y, rr[g][k].z, rr[g][k].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)} +
+                              f32x2{__uint_as_float(r4[q] << 16), __uint_as_float(r4[q] & 0xffff0000u)};
+              a4[q] = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+            }
+            v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+          }
+          *reinterpret_cast<uint4*>(obase + eoff[g][k]) = v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)};
+            s1[g][q] += t;
+            s2[g][q] = __builtin_elementwise_fma(t, t, s2[g][q]);
           }
         }
-        __syncthreads();
-        const int n = img0 + ((g * RG) >> p.thw_shift);
-        if (tid < BN && nb * BN + tid < p.Cout && n < p.N) {
-          float t1 = 0.f, t2 = 0.f;
-          for (int q = 0; q < PR; ++q) { t1 += red[(q * BN + tid) * 2]; t2 += red[(q * BN + tid) * 2 + 1]; }
-          // slab of this group inside its image: (tile of the image) * SGROUPS + g for one-image tiles
-          const int slab = p.TI == 1 ? (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g : 0;
-          float* dst = p.stats + (((long long)n * p.stat_slabs + slab) * p.Cout + nb * BN + tid) * 2;
-          dst[0] = t1;
-          dst[1] = t2;
+      ADM_TSTAMP(ltile_done, 5);
+      if (p.stats) {
+        // reduce the PR row-partials of every channel through LDS (fixed order: bitwise reproducible)
+        float* red = reinterpret_cast<float*>(stg);  // [PR][BN][2]
+#pragma unroll
+        for (int g = 0; g < SGROUPS; ++g) {
+          __syncthreads();  // staging buffer (or the previous group's partials) fully consumed
+          if (prow < PR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              red[(prow * BN + sg * 8 + e) * 2 + 0] = s1[g][e >> 1][e & 1];
+              red[(prow * BN + sg * 8 + e) * 2 + 1] = s2[g][e >> 1][e & 1];
+            }
+          }
+          __syncthreads();
+          if (sdst[g]) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int q = 0; q < PR; ++q) { t1 += red[(q * BN + tid) * 2]; t2 += red[(q * BN + tid) * 2 + 1]; }
+            sdst[g][0] = t1;
+            sdst[g][1] = t2;
+          }
         }
       }
-    }
-    ADM_TSTAMP(6);
-    return;
-  }
-  // fp32 NCHW (output head / stem backward): few channels, direct stores
+      ADM_TSTAMP(ltile_done, 6);
+    } else {
+      // fp32 NCHW (output head / stem backward): few channels, direct stores
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = (wm * TM + i) * 16 + lc;
-    const int ti = m / (p.TH * p.TW), rem = m % (p.TH * p.TW);
-    const int n = img0 + ti, y = y0 + rem / p.TW, x = x0 + rem % p.TW;
-    if (n >= p.N) continue;
+      for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 16 + lc;
+        const int ti = m >> p.thw_shift, rem = m & ((1 << p.thw_shift) - 1);
+        const int n = img0 + ti, y = y0 + (rem >> p.tw_shift), x = x0 + (rem & ((1 << p.tw_shift) - 1));
+        if (n >= p.N) continue;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int ch0 = nb * BN + (wn * TN + j) * 16 + lq * 4;
+        for (int j = 0; j < TN; ++j) {
+          const int ch0 = nb * BN + (wn * TN + j) * 16 + lq * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ch = ch0 + e;
-        if (ch >= p.Cout) continue;
-        reinterpret_cast<float*>(p.out)[(((long long)n * p.Cout + ch) * p.H + y) * p.W + x] = acc[i][j][e] + p.bias[ch];
+          for (int e = 0; e < 4; ++e) {
+            const int ch = ch0 + e;
+            if (ch >= p.Cout) continue;
+            reinterpret_cast<float*>(p.out)[(((long long)n * p.Cout + ch) * p.H + y) * p.W + x] =
+                acc[i][j][e] + (ch0 + 3 < p.Cout ? 0.f : p.bias[ch]);
+          }
+        }
+      }
+      if (more) {
+        tl = tnext;
+        ltile = tstart + tl;
+        tile_origin(ltile, nb, mt, img0, y0, x0);
+        tile_setup();
+              first_loads(lq);
+        __syncthreads();
+        first_park();
       }
     }
+    if (!more) break;
   }
 }
 
@@ -787,23 +935,33 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
 
 template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
 int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
+  constexpr int NT = 64 * WM * WN;
   constexpr int BN = WN * TN * 16;
-  constexpr int smem = conv_smem_bytes<64 * WM * WN, BN, HALO, WM * TM * 16>();
-  static bool attr_set_dev[64] = {};
+  constexpr int smem = ConvLds<NT, BN, HALO, WM * TM * 16>::BYTES;
+  static_assert(smem <= 160 * 1024, "conv_kernel LDS map exceeds the CU's 160 KB");
+  // per device: opt in to the LDS size once, and size the persistent grid to the resident blocks
+  static int slots_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  bool& attr_set = attr_set_dev[dev & 63];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  int& slots = slots_dev[dev & 63];
+  const void* fn = reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>);
+  if (slots == 0) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    int per_cu = 0, ncu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NT, smem);
+    if (e != hipSuccess || per_cu <= 0) ADM_FAIL((int)e, "adm_conv: block of %d threads / %d B LDS is not launchable", NT, smem);
+    e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || ncu <= 0) ADM_FAIL((int)e, "adm_conv: hipDeviceGetAttribute: %s", hipGetErrorString(e));
+    slots = per_cu * ncu;
   }
   ConvK kk = k;
   kk.nblocks_n = (k.Cout + BN - 1) / BN;
-  const long long blocks = (long long)m_tiles * kk.nblocks_n;
-  ADM_REQUIRE(blocks < (1ll << 31), ADM_E_SHAPE, "adm_conv: grid too large");
-  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>), dim3((unsigned)blocks), dim3(64 * WM * WN), smem, s, kk);
+  const long long tiles = (long long)m_tiles * kk.nblocks_n;
+  ADM_REQUIRE(tiles < (1ll << 31), ADM_E_SHAPE, "adm_conv: too many tiles");
+  kk.total_tiles = (int)tiles;
+  const unsigned blocks = (unsigned)(tiles < slots ? tiles : slots);
+  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>), dim3(blocks), dim3(NT), smem, s, kk);
   return adm_check_launch("adm_conv");
 }
 
@@ -829,6 +987,9 @@ bool conv_geometry(ConvK& k, int BM, int taps, int halo_max) {
   if ((k.TW & (k.TW - 1)) || (k.TH & (k.TH - 1))) return false;
   k.tw_shift = __builtin_ctz(k.TW);
   k.thw_shift = __builtin_ctz(k.TH * k.TW);
+  const unsigned hw2 = (unsigned)(k.TW + 2 * pad), hpi = (unsigned)(k.TH + 2 * pad) * hw2;
+  k.rcp_hw2 = ((1u << 20) + hw2 - 1) / hw2;
+  k.rcp_hpi = ((1u << 20) + hpi - 1) / hpi;
   return true;
 }
 

@@ -64,11 +64,15 @@ def main():
         hw_id, xcc = buf[:, 14].astype(np.int64), buf[:, 15].astype(np.int64) & 0xF
         cu = (xcc << 8) | (((hw_id >> 13) & 7) << 5) | (((hw_id >> 12) & 1) << 4) | ((hw_id >> 8) & 0xF)
         ncu = len(np.unique(cu))
-        names = ["prologue", "k-loop", "epi:wait", "epi:stage0", "epi:sweep0", "epi:rest"]
+        clk = ((buf[:, 9].astype(np.int64) - buf[:, 8].astype(np.int64)) / np.maximum(t[:, 2] - t[:, 1], 1)) * 100.0  # MHz
+        names = ["wait", "k-loop", "switch+stage", "park-next", "sweep", "stats"]
+        sub = buf[:, [2, 10, 11, 12, 13, 3]].astype(np.int64)
+        subd = np.diff(sub, axis=1) / tick
         tot = (t[:, 6] - t[:, 0]) / tick
-        print(f"{name:28s} kernel {kern_us:8.1f} us | {len(buf)} blocks on {ncu} CUs | span {span:8.1f} us | block {tot.mean():7.2f} us "
+        print(f"{name:28s} kernel {kern_us:8.1f} us | {len(buf)} tiles on {ncu} CUs | span {span:8.1f} us | k-loop clock {np.median(clk):6.0f} MHz | block {tot.mean():7.2f} us "
               f"(sum/CU {tot.sum() / ncu:8.1f}) | "
-              + "  ".join(f"{nm} {d[:, i].mean():6.2f}" for i, nm in enumerate(names)))
+              + "  ".join(f"{nm} {d[:, i].mean():6.2f}" for i, nm in enumerate(names))
+              + " | switch: " + "  ".join(f"{nm} {subd[:, i].mean():5.2f}" for i, nm in enumerate(["bases", "stage", "setup+dma+addr", "loads", "barrier"])))
 
 
 if __name__ == "__main__":
