@@ -40,8 +40,13 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+#ifndef ADM_CONV_KS2
+#define ADM_CONV_KS2 0   // 1: 1x1 convs use 64-channel stages where the channel counts allow
+#endif
 constexpr int KC = 32;           // input channels per chunk (= one MFMA K)
-constexpr int ROWB = 96;         // LDS bytes per halo pixel: 64 data + 32 pad
+// LDS bytes per halo pixel: 64 data bytes per K-step of the stage + 32 pad (conflict-free ds_read_b128 fragments)
+constexpr int conv_rowb(int ks) { return 64 * ks + 32; }
+constexpr int ROWB = conv_rowb(1);
 constexpr int TI_MAX = 4;
 constexpr unsigned OOB = 0x80000000u;  // buffer-load offset beyond num_records -> returns 0
 
@@ -81,14 +86,14 @@ constexpr int conv_smem_bytes() {
 // LDS map of conv_kernel: halo[0] | halo[1] ... | affine tables.  The epilogue's output staging (whole tile,
 // bf16 rows + 16 B pad) and the statistics reduction overlay halo[1] onwards, never halo[0] or the affine
 // tables: those receive the NEXT tile's first chunk while the current tile is being stored.
-template <int NT, int BN, int HALO, int BM>
+template <int NT, int BN, int HALO, int BM, int KS>
 struct ConvLds {
-  static constexpr int HB = halo_slots<NT, HALO>() * ROWB;   // one halo buffer
+  static constexpr int HB = ((HALO * 4 * KS + NT - 1) / NT) * (NT / (4 * KS)) * conv_rowb(KS);  // one halo buffer (whole passes)
   static constexpr int STG = BM * (BN * 2 + 16);             // output staging
   static constexpr int RED = NT * 64;                        // statistics reduction [NT*8/BN rows][BN][2] floats
   static constexpr int OVL = (STG > RED ? STG : RED) > HB ? (STG > RED ? STG : RED) : HB;
   static constexpr int ABUF = (HB + OVL + 15) & ~15;
-  static constexpr int BYTES = ABUF + 2 * TI_MAX * 64 * 4;
+  static constexpr int BYTES = ABUF + 2 * 2 * TI_MAX * 32 * KS * 4;   // a | b, two stages each
 };
 
 #ifdef ADM_CONV_TIMING
@@ -125,17 +130,25 @@ __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned vo
 // dependent latencies) or the block launch gap; here the NEXT tile's first loads are issued before the
 // current tile's accumulators are staged and stored, and land in LDS (halo buffer 0, which the output
 // staging does not overlay) while the epilogue runs.
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO, int KS>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 conv_kernel(const ConvK p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
-  constexpr int PASSES = (HALO * 4 + NT - 1) / NT;
+  // a STAGE is what one halo buffer holds: KS 32-channel K-steps of every halo pixel (3x3: KS = 1, the 9 taps
+  // give a stage its depth; 1x1: KS = 2 where the channel counts allow, or the loop is all barriers)
+  constexpr int KCS = KC * KS;             // channels per stage
+  constexpr int SEGP = 4 * KS;             // 16-byte segments per halo pixel
+  constexpr int SEGSH = KS == 1 ? 2 : 3;   // log2(SEGP)
+  constexpr int ROWB = conv_rowb(KS);      // LDS bytes per halo pixel
+  constexpr int PASSES = (HALO * SEGP + NT - 1) / NT;
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   constexpr int SGROUPS = stat_groups<BM>();  // statistics slabs per tile
-  using Lds = ConvLds<NT, BN, HALO, BM>;
+  using Lds = ConvLds<NT, BN, HALO, BM, KS>;
+  static_assert(KS == 1 || (KS == 2 && TAPS == 1), "multi-step stages are a 1x1 feature");
   static_assert(TAPS == 1 || PASSES <= TAPS - 1, "halo passes must fit in the taps of one chunk");
+  static_assert(PASSES <= 8, "ti_pack holds 8 passes");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const halo = smem;               // [2][Lds::HB]
@@ -164,20 +177,20 @@ conv_kernel(const ConvK p) {
   const int HP = p.TI * HPI;
   const int Cin = p.C0 + p.C1;
   const int HWimg = p.H * p.W;
-  const int chunks = Cin / KC;
-  const int c0chunks = p.C0 / KC;
+  const int chunks = Cin / KCS;            // stages of the K loop
+  const int c0chunks = p.C0 / KCS;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.Cout * 4, 0x00020000);
 
-  // ---- halo staging geometry: 16-byte segment s = tid + pass*NT -> (halo pixel s>>2, segment s&3)
+  // ---- halo staging geometry: 16-byte segment s = tid + pass*NT -> (halo pixel s / SEGP, segment s % SEGP)
   unsigned ti_pack = 0;    // image-in-tile of each pass, 4 bits each
 #pragma unroll
   for (int ps = 0; ps < PASSES; ++ps) {
-    const int hp = (tid + ps * NT) >> 2;
+    const int hp = (tid + ps * NT) >> SEGSH;
     if (hp < HP) ti_pack |= (unsigned)(hp / HPI) << (4 * ps);
   }
-  const int seg = tid & 3;  // NT % 4 == 0 -> the same channel segment in every pass
-  const int hslot = (tid >> 2) * ROWB + seg * 16;  // LDS byte offset of pass 0's slot; pass ps adds ps*(NT/4)*ROWB
+  const int seg = tid & (SEGP - 1);  // NT % SEGP == 0 -> the same channel segment in every pass
+  const int hslot = (tid >> SEGSH) * ROWB + seg * 16;  // LDS byte offset of pass 0's slot; pass ps adds ps*(NT/SEGP)*ROWB
 
   // ---- MFMA fragment addressing
   // LDS byte offset of a lane's pixel row = lane part (its pixel inside the 16-pixel tile, its
@@ -231,7 +244,7 @@ conv_kernel(const ConvK p) {
     asm volatile("" : "+v"(tid_s));
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int hp = (tid_s + ps * NT) >> 2;
+      const int hp = (tid_s + ps * NT) >> SEGSH;
       const int ti = (int)(((unsigned)hp * p.rcp_hpi) >> 20), rem = hp - ti * HPI;
       const int ry = (int)(((unsigned)rem * p.rcp_hw2) >> 20), rx = rem - ry * HW2;
       const int y = y0 + ry - PAD, x = x0 + rx - PAD;
@@ -239,22 +252,24 @@ conv_kernel(const ConvK p) {
       pixrel[ps] = ok ? (ti * p.H + y) * p.W + x : -1;
     }
     // LDS-DMA of the tile's first chunk (see first_park): raw halo chunk 0, lane-linear into halo[0] ...
-    const int seg_s = tid_s & 3, lane_s = tid_s & 63;
+    const int seg_s = tid_s & (SEGP - 1), lane_s = tid_s & 63;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * p.C0 + seg_s * 8) * 2u : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(halo + (ps * NT + wave * 64) * 16), 16, (int)voff, 0, 0, 0);
     }
-    // ... and the affine tables of chunks 0 and 1 (they are staged two chunks ahead): the LDS table is
-    // a[buf][ti][32] followed by b[buf][ti][32], so ONE wave-instruction moves each half: wave 0 the a half,
-    // wave 1 the b half, lane = buf*32 + ti*8 + part -> 4 floats from row n of chunk buf (32-bit offsets
-    // into a descriptor over the whole [N][Cin] table)
+    // ... and the affine tables of stages 0 and 1 (they are staged two stages ahead): the LDS table is
+    // a[buf][ti][KCS] followed by b[buf][ti][KCS]; each half is 2*KCS lanes x 16 B, lane-linear, so KS
+    // wave-instructions move it: waves 0..KS-1 the a half, waves KS..2KS-1 the b half (32-bit offsets into
+    // a descriptor over the whole [N][Cin] table)
     if constexpr (PRO != 0) {
-      if (wave < 2) {
-        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(wave == 0 ? p.aa : p.ab), 0, p.N * Cin * 4, 0x00020000);
-        const int ti = (lane_s >> 3) & 3, n = min(img0 + ti, p.N - 1);
-        const unsigned voff = ti < p.TI ? (unsigned)(n * Cin + min(lane_s >> 5, chunks - 1) * KC + (lane_s & 7) * 4) * 4u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(abuf + wave * (2 * TI_MAX * 32)), 16, (int)voff, 0, 0, 0);
+      if (wave < 2 * KS) {
+        const int half = wave / KS, idx = (wave % KS) * 64 + lane_s;  // idx = (buf * TI_MAX + ti) * (KCS/4) + part
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(half == 0 ? p.aa : p.ab), 0, p.N * Cin * 4, 0x00020000);
+        const int buf = idx / (TI_MAX * (KCS / 4)), ti = (idx / (KCS / 4)) % TI_MAX, part = idx % (KCS / 4);
+        const int n = min(img0 + ti, p.N - 1);
+        const unsigned voff = ti < p.TI ? (unsigned)(n * Cin + min(buf, chunks - 1) * KCS + part * 4) * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(abuf + half * (2 * TI_MAX * KCS) + (wave % KS) * 256), 16, (int)voff, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -269,38 +284,41 @@ conv_kernel(const ConvK p) {
   // activation segment `ps` of chunk c (the descriptor select is scalar; out-of-image lanes read zero)
   auto halo_load = [&](int c, int ps) -> uint4 {
     const bool first = c < c0chunks;
-    const int cs = first ? p.C0 : p.C1, co = (first ? c : c - c0chunks) * KC;
+    const int cs = first ? p.C0 : p.C1, co = (first ? c : c - c0chunks) * KCS;
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
     return bufload16(rs, voff, 0);
   };
-  // affine table of chunk c: threads < TI*16 fetch one float4 of a (parts 0-7) or b (parts 8-15)
+  // affine table of stage c: threads < TI * KCS/2 fetch one float4 of a (parts < KCS/4) or b
+  constexpr int APT = KCS / 2;             // threads per image of the tile
   auto affine_load = [&](int c, int im0) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PRO != 0) {
-      if (tid < p.TI * 16) {
-        const int n = min(im0 + (tid >> 4), p.N - 1);
-        v = *reinterpret_cast<const float4*>(((tid & 15) < 8 ? p.aa : p.ab) + (long long)n * Cin + c * KC + (tid & 7) * 4);
+      if (tid < p.TI * APT) {
+        const int n = min(im0 + tid / APT, p.N - 1), part = tid % APT;
+        v = *reinterpret_cast<const float4*>((part < APT / 2 ? p.aa : p.ab) + (long long)n * Cin + c * KCS + (part % (APT / 2)) * 4);
       }
     }
     return v;
   };
   auto affine_park = [&](float4 v, int buf) {
     if constexpr (PRO != 0) {
-      if (tid < p.TI * 16)
-        *reinterpret_cast<float4*>(abuf + ((tid & 15) < 8 ? 0 : 2 * TI_MAX * 32) + (buf * TI_MAX + (tid >> 4)) * 32 + (tid & 7) * 4) = v;
+      if (tid < p.TI * APT) {
+        const int part = tid % APT;
+        *reinterpret_cast<float4*>(abuf + (part < APT / 2 ? 0 : 2 * TI_MAX * KCS) + (buf * TI_MAX + tid / APT) * KCS + (part % (APT / 2)) * 4) = v;
+      }
     }
   };
   // transform (fp32 affine [+ SiLU], rounded to bf16) and park a segment; zero padding stays exactly zero
   auto halo_write = [&](uint4 v, int ps, int buf) {
     if constexpr (PRO != 0) {
       const int ti = (ti_pack >> (4 * ps)) & 15;
-      const float* ab = abuf + (buf * TI_MAX + ti) * 32 + seg * 8;
+      const float* ab = abuf + (buf * TI_MAX + ti) * KCS + seg * 8;
       float a8[8], b8[8];
       *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ab);
       *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ab + 4);
-      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * 32);
-      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * 32 + 4);
+      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * KCS);
+      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * KCS + 4);
       uint32_t u[4] = {v.x, v.y, v.z, v.w};
       const bool valid = pixrel[ps] >= 0;
 #pragma unroll
@@ -314,7 +332,7 @@ conv_kernel(const ConvK p) {
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
     }
-    *reinterpret_cast<uint4*>(halo + buf * Lds::HB + ps * (NT / 4) * ROWB + hslot) = v;
+    *reinterpret_cast<uint4*>(halo + buf * Lds::HB + ps * (NT / SEGP) * ROWB + hslot) = v;
   };
   auto load_w = [&](int step, uint4 (&dst)[TN]) {
 #pragma unroll
@@ -358,16 +376,24 @@ conv_kernel(const ConvK p) {
   // The narrow register loads (first weight fragments: 3x3 ring of 3 K-steps, two in flight; 1x1 ring of
   // 4, three in flight, plus the activation segments of chunk 1; the bias fragment the accumulators start
   // from) go out once the accumulators' registers are free.
-  constexpr int WRING = TAPS == 9 ? 3 : 4;
+  constexpr int WRING = TAPS == 9 ? 3 : (KS == 1 ? 4 : 2 * KS);
   uint4 wr[WRING][TN];
   uint4 ring[2][PASSES];
   float4 bs[TN];
   const int last = chunks - 1;
   auto first_loads = [&](int lq_) {
-    load_w(0, wr[0]);
-    load_w(min(1, TAPS == 9 ? 9 * chunks - 1 : last), wr[1]);
-    if constexpr (TAPS == 1) {
-      load_w(min(2, last), wr[2]);
+    if constexpr (TAPS == 9) {
+      load_w(0, wr[0]);
+      load_w(1, wr[1]);
+    } else {
+      if constexpr (KS == 1) {
+        load_w(0, wr[0]);
+        load_w(min(1, last), wr[1]);
+        load_w(min(2, last), wr[2]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) load_w(ks, wr[ks]);  // stage 0's K-steps
+      }
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(1, last), ps);
     }
@@ -445,30 +471,57 @@ conv_kernel(const ConvK p) {
       for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
       chunk(chunks - 1, std::false_type{});
     } else {
-      // 1x1: one K-step (TM*TN MFMAs per wave) per chunk, so HBM/L2 latency must be covered by depth, not
-      // by the taps: activation segments are fetched 2 chunks ahead (register ring of 2), weight fragments
-      // 3 chunks ahead (ring of 4); one barrier per chunk.  The loop is unrolled by 4 so that every ring
-      // slot is a compile-time register; indices past the last chunk are clamped (harmless re-reads).
-      auto body = [&](int c, auto sa_, auto sw_) {
-        constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
-        if (c > last) return;
-        const int c2 = min(c + 2, last);
-        affine_park(affine_load(c2, img0), c & 1);
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
-        load_w(min(c + 3, last), wr[(SW + 3) % 4]);
-        mfma_tap(halo + (c & 1) * Lds::HB, wr[SW]);
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
-        __syncthreads();
-      };
+      // 1x1: a stage is KS K-steps (KS*TM*TN MFMAs per wave) and ends in the loop's only barrier, so HBM/L2
+      // latency must be covered by depth, not by taps: activation segments are fetched 2 stages ahead (register
+      // ring of 2), weight fragments 3 K-steps (KS = 1: ring of 4) or one stage (KS = 2: ring of 2 stages) ahead.
+      // The loop is unrolled so that every ring slot is a compile-time register; indices past the last stage are
+      // clamped (harmless re-reads).
+      // (Measured, MI355X: neither 64-channel stages nor running the two waves of a SIMD in opposite phases --
+      // MFMAs of stage c against transform + park of stage c+1 -- shortened this loop: ~1 us per K-step either way.)
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-      for (int c0 = 0; c0 < chunks; c0 += 4) {
-        body(c0, I0{}, I0{});
-        body(c0 + 1, I1{}, I1{});
-        body(c0 + 2, I0{}, I2{});
-        body(c0 + 3, I1{}, I3{});
+      if constexpr (KS == 1) {
+        auto body = [&](int c, auto sa_, auto sw_) {
+          constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
+          if (c > last) return;
+          const int c2 = min(c + 2, last);
+          affine_park(affine_load(c2, img0), c & 1);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
+          load_w(min(c + 3, last), wr[(SW + 3) % 4]);
+          mfma_tap(halo + (c & 1) * Lds::HB, wr[SW]);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
+          __syncthreads();
+        };
+        for (int c0 = 0; c0 < chunks; c0 += 4) {
+          body(c0, I0{}, I0{});
+          body(c0 + 1, I1{}, I1{});
+          body(c0 + 2, I0{}, I2{});
+          body(c0 + 3, I1{}, I3{});
+        }
+      } else {
+        auto body = [&](int c, auto sa_) {
+          constexpr int SA = decltype(sa_)::value;  // parity of c
+          if (c > last) return;
+          const int c2 = min(c + 2, last);
+          // weights first: the wait for them at the next stage must not also drain the (slower, HBM) activation
+          // loads issued behind them -- vmcnt retires in order
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) load_w(min(c + 1, last) * KS + ks, wr[(SA ^ 1) * KS + ks]);
+          affine_park(affine_load(c2, img0), c & 1);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) mfma_tap(halo + SA * Lds::HB + ks * 64, wr[SA * KS + ks]);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, SA ^ 1);
+          __syncthreads();
+        };
+        for (int c0 = 0; c0 < chunks; c0 += 2) {
+          body(c0, I0{});
+          body(c0 + 1, I1{});
+        }
       }
     }
     ADM_TSTAMP(ltile, 2);
@@ -933,18 +986,18 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
   }
 }
 
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO, int KS>
 int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = WN * TN * 16;
-  constexpr int smem = ConvLds<NT, BN, HALO, WM * TM * 16>::BYTES;
+  constexpr int smem = ConvLds<NT, BN, HALO, WM * TM * 16, KS>::BYTES;
   static_assert(smem <= 160 * 1024, "conv_kernel LDS map exceeds the CU's 160 KB");
   // per device: opt in to the LDS size once, and size the persistent grid to the resident blocks
   static int slots_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   int& slots = slots_dev[dev & 63];
-  const void* fn = reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>);
+  const void* fn = reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS>);
   if (slots == 0) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -961,16 +1014,16 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   ADM_REQUIRE(tiles < (1ll << 31), ADM_E_SHAPE, "adm_conv: too many tiles");
   kk.total_tiles = (int)tiles;
   const unsigned blocks = (unsigned)(tiles < slots ? tiles : slots);
-  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO>), dim3(blocks), dim3(NT), smem, s, kk);
+  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS>), dim3(blocks), dim3(NT), smem, s, kk);
   return adm_check_launch("adm_conv");
 }
 
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int KS>
 int launch_conv(const ConvK& k, int prologue, int m_tiles, hipStream_t s) {
   switch (prologue) {
-    case 0: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 0>(k, m_tiles, s);
-    case 1: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 1>(k, m_tiles, s);
-    default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2>(k, m_tiles, s);
+    case 0: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 0, KS>(k, m_tiles, s);
+    case 1: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 1, KS>(k, m_tiles, s);
+    default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2, KS>(k, m_tiles, s);
   }
 }
 
@@ -996,20 +1049,26 @@ bool conv_geometry(ConvK& k, int BM, int taps, int halo_max) {
 template <int WM, int WN, int TM, int TN, int OCC>
 int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
   constexpr int BM = WM * TM * 16;
-  // halo capacity: one image (TH+2)(TW+2) patch, or TI images of small maps
+  // halo capacity: one (TH+2)(TW+2) patch of one image for the 256-pixel tiles (maps >= 16x16); TI whole images
+  // of a small map for the 128-pixel tiles (adm_conv sends 8x8 maps there)
   if (taps == 9) {
-    if (conv_geometry(k, BM, 9, (BM == 256) ? 324 : 180) && k.TI == 1) {
-      const int m_tiles = k.N * k.tiles_x * k.tiles_y;
-      return launch_conv<WM, WN, TM, TN, OCC, 9, (BM == 256) ? 324 : 180>(k, prologue, m_tiles, s);
-    }
-    if (conv_geometry(k, BM, 9, (BM == 256) ? 400 : 200)) {
-      const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
-      return launch_conv<WM, WN, TM, TN, (BM == 256 ? 1 : OCC), 9, (BM == 256) ? 400 : 200>(k, prologue, m_tiles, s);
+    if constexpr (BM == 256) {
+      if (conv_geometry(k, BM, 9, 324) && k.TI == 1) {
+        const int m_tiles = k.N * k.tiles_x * k.tiles_y;
+        return launch_conv<WM, WN, TM, TN, OCC, 9, 324, 1>(k, prologue, m_tiles, s);
+      }
+    } else {
+      if (conv_geometry(k, BM, 9, 200)) {
+        const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
+        return launch_conv<WM, WN, TM, TN, OCC, 9, 200, 1>(k, prologue, m_tiles, s);
+      }
     }
   } else {
     if (conv_geometry(k, BM, 1, BM)) {
       const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
-      return launch_conv<WM, WN, TM, TN, OCC, 1, BM>(k, prologue, m_tiles, s);
+      // 64-channel stages (two K-steps per barrier) when neither source straddles a stage
+      if (ADM_CONV_KS2 && k.C0 % 64 == 0 && k.C1 % 64 == 0) return launch_conv<WM, WN, TM, TN, OCC, 1, BM, ADM_CONV_KS2 ? 2 : 1>(k, prologue, m_tiles, s);
+      return launch_conv<WM, WN, TM, TN, OCC, 1, BM, 1>(k, prologue, m_tiles, s);
     }
   }
   ADM_FAIL(ADM_E_SHAPE, "adm_conv: %dx%d feature map does not tile into %d-pixel patches (need >= 8x8, power of two)",
@@ -1017,20 +1076,15 @@ int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
 }
 
 
-// tiling variant (output-tile width): 5 = 192, 6 = 128 (8 waves); 1 = 128, 2 = 96, 4 = 64, 3 = 16 (4 waves).
-// Measured on MI355X (tools/conv_bench.py): the 8-wave tiles share one halo staging + prologue transform
-// among twice as many MFMAs and win whenever they pad <= 10 %; otherwise the 96-wide tile is the fastest
-// per useful column unless it pads > 15 % (then 64-wide); on the 128-pixel tiles of 8x8 maps the
-// 128-wide tile wins when it pads no more than the 96-wide one.
+// tiling variant (output-tile width): 5 = 192, 6 = 128 (8 waves); 3 = 16 (4 waves: output head / stem
+// backward); 7 = the 32x32x16 MFMA kernel (explicit only).  Auto: the width that pads Cout least, 192 on a tie
+// (measured on MI355X, tools/conv_bench.py: the 8-wave tiles share one halo staging + prologue transform among
+// twice as many MFMAs as the retired 4-wave 128 / 96 / 64-wide tilings and beat them wherever those padded less).
 int pick_variant(const adm_conv_args* a) {
   if (a->variant != 0) return a->variant;
-  const int w192 = ((a->cout + 191) / 192) * 192, w128 = ((a->cout + 127) / 128) * 128;
-  const int w96 = ((a->cout + 95) / 96) * 96, w64 = ((a->cout + 63) / 64) * 64;
   if (a->cout <= 16) return 3;
-  if (w192 * 10 <= a->cout * 11) return 5;
-  if (w128 * 10 <= a->cout * 11) return 6;
-  if (a->h * a->w <= 64) return (w128 <= w96) ? 1 : 2;
-  return (w96 * 0.85 <= w64) ? 2 : 4;
+  const int w192 = ((a->cout + 191) / 192) * 192, w128 = ((a->cout + 127) / 128) * 128;
+  return w192 <= w128 ? 5 : 6;
 }
 
 // slabs of the fused output statistics: one per 256-pixel tile on maps >= 16x16, one per image on 8x8
@@ -1142,10 +1196,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
   const bool small_map = a->h * a->w <= 64;
   switch (variant) {
-    case 1: return small_map ? dispatch_conv<2, 2, 4, 4, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 4, 1>(k, a->taps, a->prologue, s);
-    case 2: return small_map ? dispatch_conv<2, 2, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 3, 2>(k, a->taps, a->prologue, s);
     case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, a->prologue, s);  // 256 x 16 (output head / stem backward)
-    case 4: return small_map ? dispatch_conv<2, 2, 4, 2, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 2, 8, 2, 2>(k, a->taps, a->prologue, s);
     // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs
     case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, a->prologue, s);
     // 8 waves, 128-wide tile (channel counts that are multiples of 128 but not of 192: the classifier)

@@ -28,17 +28,10 @@ CONV_PROFILE = None
 
 def conv_variant(cout: int, hw: int) -> int:
     """Tiling variant picked for an output-channel count and map size (mirrors adm_conv's auto rule)."""
-    w192, w128 = -(-cout // 192) * 192, -(-cout // 128) * 128
-    w96, w64 = -(-cout // 96) * 96, -(-cout // 64) * 64
     if cout <= 16:
         return 3
-    if w192 * 10 <= cout * 11:
-        return 5
-    if w128 * 10 <= cout * 11:
-        return 6
-    if hw <= 64:
-        return 1 if w128 <= w96 else 2
-    return 2 if w96 * 0.85 <= w64 else 4
+    w192, w128 = -(-cout // 192) * 192, -(-cout // 128) * 128
+    return 5 if w192 <= w128 else 6
 
 
 def _stream() -> int:

@@ -160,7 +160,7 @@ def main():
     roof = None
     if ops.CONV_PROFILE is not None:
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        # dominant kernel symbol: conv_kernel<2, 4, 8, 3, 2, 9, 324, 2> = fused GN+SiLU prologue, 3x3 conv,
+        # dominant kernel symbol: conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> = fused GN+SiLU prologue, 3x3 conv,
         # 256-pixel x 192-channel tile, 8 waves
         if args.conv_breakdown and rank == 0:
             agg = {}
@@ -180,7 +180,7 @@ def main():
             if os.path.exists(tp):  # HBM bytes per launch from separate rocprofv3 --pmc passes (see the file)
                 with open(tp) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)",
+            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)",
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": len(dom), "avg_launch_us": round(ms * 1e3 / len(dom), 2),

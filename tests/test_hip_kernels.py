@@ -173,9 +173,8 @@ CONV_CASES = [
     (2, 16, 64, 0, 192, 1, 1, False, False, 0),  # qkv projection (GN, no SiLU)
     (2, 8, 96, 0, 96, 1, 0, True, False, 0),     # proj_out + residual
     (5, 8, 64, 64, 64, 1, 0, False, False, 0),   # skip 1x1 on a concat
-    (1, 16, 64, 0, 256, 9, 2, False, False, 1),
-    (1, 16, 64, 0, 256, 9, 2, False, False, 2),
-    (1, 16, 64, 0, 256, 9, 2, False, False, 4),
+    (1, 16, 64, 0, 256, 9, 2, False, False, 5),   # Cout padded to two 192-wide blocks
+    (1, 16, 64, 0, 64, 9, 2, False, False, 6),    # Cout below one 128-wide block
     (2, 32, 96, 0, 16, 9, 2, False, False, 3),
     (2, 16, 64, 0, 192, 9, 2, True, False, 5),
     (2, 16, 64, 0, 128, 9, 2, True, False, 6),
