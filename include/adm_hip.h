@@ -147,7 +147,8 @@ typedef struct adm_conv_args {
   int32_t taps;      /* 9 or 1 */
   int32_t prologue;  /* 0,1,2  */
   int32_t out_mode;  /* 0,1    */
-  int32_t variant;   /* tiling variant, 0 = auto */
+  int32_t variant;   /* tiling variant: 0 = auto (5 or 6 by least Cout padding, 3 for cout <= 16); 5 = 192-wide and
+                        6 = 128-wide 8-wave tiles; 3 = 16-wide (output head / stem backward); 7 = 32x32x16 MFMA kernel */
   float* out_stats;  /* optional: fp32 [N][slabs][cout][2] = per-(image, slab, channel) sum and sum of squares of
                         the bf16 OUTPUT, accumulated in the epilogue (slabs = adm_conv_stat_slabs(args)); the
                         consumer's GroupNorm then needs no adm_gn_partial pass over the tensor */
