@@ -50,6 +50,8 @@ attn_kernel(const AttnK p) {
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
             vcol = p.v_off + hd * p.head_stride;
 
+  // one descriptor over this image's T rows: queries / keys beyond T read as zeros (no bounds branches)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
   // Q^T fragments: lane (query lc, quarter lq) holds Q[query][ks*32 + 8*lq .. +8]
   bf16x8 qf[2][KS];
 #pragma unroll
@@ -57,8 +59,7 @@ attn_kernel(const AttnK p) {
     const int q = qbase + qt * 16 + lc;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (q < p.T) v = *reinterpret_cast<const uint4*>(base + (long long)q * p.C3 + qcol + ks * 32 + lq * 8);
+      const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
       qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
     }
   }
@@ -71,8 +72,8 @@ attn_kernel(const AttnK p) {
   float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
   AdmTileRegs<KT, D, 256> kr, vr;
-  kr.load(base, p.C3, kcol, 0, p.T, tid);
-  vr.load(base, p.C3, vcol, 0, p.T, tid);
+  kr.load_buf(rs, p.C3, kcol, 0, tid);
+  vr.load_buf(rs, p.C3, vcol, 0, tid);
   kr.store(Ks[0], KROW, tid);
   vr.store(Vs[0], KROW, tid);
   __syncthreads();
@@ -83,8 +84,8 @@ attn_kernel(const AttnK p) {
     const int cur = kt0 & 1;
     const bool next = kt0 + 1 < ntiles;
     if (next) {
-      kr.load(base, p.C3, kcol, k0 + KT, p.T, tid);
-      vr.load(base, p.C3, vcol, k0 + KT, p.T, tid);
+      kr.load_buf(rs, p.C3, kcol, k0 + KT, tid);
+      vr.load_buf(rs, p.C3, vcol, k0 + KT, tid);
     }
     const uint16_t* Kc = Ks[cur];
     const uint16_t* Vc = Vs[cur];
@@ -102,12 +103,14 @@ attn_kernel(const AttnK p) {
         kfr[kt][ks] = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 st[4][2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) st[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < 2; ++qt)
+        st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt][0], qf[qt][0], zero4, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
@@ -126,6 +129,7 @@ attn_kernel(const AttnK p) {
     for (int qt = 0; qt < 2; ++qt) {
       float mx = -1e30f;
       if (ragged) {  // only the last tile of a sequence whose length is not a multiple of 64
+        asm volatile("" ::: "memory");  // keep this a (wave-uniform) branch: if-converted it is 32 compares + selects per tile
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -141,16 +145,21 @@ attn_kernel(const AttnK p) {
       const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.scale_log2);
       const float mneg = -m_new * p.scale_log2;
       m_run[qt] = m_new;
-      float psum = 0.f;
+      // exponent arguments and the row sum in packed fp32 (v_pk_fma_f32 / v_pk_add_f32): this loop is VALU-bound
+      const adm_f32x2 sc2 = {p.scale_log2, p.scale_log2}, mn2 = {mneg, mneg};
+      adm_f32x2 ps2 = {0.f, 0.f};
       float pv[4][4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(st[kt][qt][r] * p.scale_log2 + mneg);
-          pv[kt][r] = e;
-          psum += e;
+        for (int h = 0; h < 2; ++h) {
+          const adm_f32x2 a = __builtin_elementwise_fma(adm_f32x2{st[kt][qt][2 * h], st[kt][qt][2 * h + 1]}, sc2, mn2);
+          const adm_f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+          pv[kt][2 * h] = e.x;
+          pv[kt][2 * h + 1] = e.y;
+          ps2 += e;
         }
+      const float psum = ps2.x + ps2.y;
       l_run[qt] = l_run[qt] * alpha + psum;
       if (__any(alpha != 1.0f)) {  // wave-uniform: skip the O rescale once the running max has settled
 #pragma unroll

@@ -7,7 +7,8 @@
 //   delta[q]   = sum_d dA[q,d] * A[q,d]
 //   P          = exp2(S * c - lse),  S = Q K^T,  c = log2(e)/sqrt(D)
 //   dV = P^T dA;   dP = dA V^T;   dS = P o (dP - delta);   dQ = dS K / sqrt(D);   dK = dS^T Q / sqrt(D)
-// Two kernels, no atomics (bitwise reproducible): dQ per 128-query block (loop over key tiles), and
+// Two kernels, no atomics (bitwise reproducible): dQ per 128-query block (loop over key tiles; it also
+// computes delta for its queries and leaves it in the workspace), and
 // dK/dV per 128-key block (loop over query tiles).  All MFMAs are v_mfma_f32_16x16x32_bf16; as in the
 // forward kernel the second product of each chain takes its B operand straight from the first
 // product's accumulators (k-order permuted identically on the LDS-transposed A side).
@@ -22,37 +23,12 @@ constexpr int PADE = 8;
 
 struct AttnBwdK {
   const uint16_t* qkv; const uint16_t* out; const uint16_t* dout; const float* lse; const float* delta;
+  float* delta_out;  // written by the dQ kernel, read (as `delta`) by the dK/dV kernel
   uint16_t* dqkv;
   int T, heads, C3, C;
   int q_off, k_off, v_off, head_stride;
   float scale_log2, inv_sqrt_d;
 };
-
-__global__ void __launch_bounds__(256)
-delta_kernel(const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout, float* __restrict__ delta,
-             int n, int t, int heads, int d) {
-  const long long items = (long long)n * t * heads;
-  const int c = heads * d;
-  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
-       it += (long long)gridDim.x * blockDim.x) {
-    const int hd = (int)(it % heads);
-    const long long row = it / heads;  // n*t + q
-    const int q = (int)(row % t), img = (int)(row / t);
-    const uint16_t* a = out + row * c + hd * d;
-    const uint16_t* g = dout + row * c + hd * d;
-    float s = 0.f;
-    for (int j = 0; j < d; j += 8) {
-      const uint4 av = *reinterpret_cast<const uint4*>(a + j), gv = *reinterpret_cast<const uint4*>(g + j);
-      const uint32_t au[4] = {av.x, av.y, av.z, av.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s += __uint_as_float(au[e] << 16) * __uint_as_float(gu[e] << 16);
-        s += __uint_as_float(au[e] & 0xffff0000u) * __uint_as_float(gu[e] & 0xffff0000u);
-      }
-    }
-    delta[((long long)img * heads + hd) * t + q] = s;
-  }
-}
 
 // ------------------------------------------------------------------------------------ dQ
 template <int D>
@@ -68,25 +44,38 @@ attn_dq_kernel(const AttnBwdK p) {
   const uint16_t* dbase = p.dout + (long long)n * p.T * p.C;
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;
 
+  // descriptors over this image's T rows: rows beyond T read as zeros, so no load carries a bounds branch and no
+  // masking is needed -- a key beyond T has K = V = 0, hence dP = 0 and its dS row multiplies a zero K row
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, p.T * p.C * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (long long)n * p.T * p.C), 0, p.T * p.C * 2, 0x00020000);
   bf16x8 qf[2][KS], gf[2][KS];
   float lse[2], dl[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qbase + qt * 16 + lc;
     const bool ok = q < p.T;
+    // delta[q] = sum_d dA[q,d] * A[q,d], from the same fragment shape as dA (lane: 8 d-values per k-step), reduced over
+    // the 4 lane quarters; written out for the dK/dV kernel that follows on the stream
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        a = *reinterpret_cast<const uint4*>(base + (long long)q * p.C3 + qcol + ks * 32 + lq * 8);
-        g = *reinterpret_cast<const uint4*>(dbase + (long long)q * p.C + hd * D + ks * 32 + lq * 8);
-      }
+      const adm_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
+      const adm_u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(rsg, (q * p.C + hd * D + ks * 32 + lq * 8) * 2, 0, 0);
+      const adm_u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rso, (q * p.C + hd * D + ks * 32 + lq * 8) * 2, 0, 0);
       qf[qt][ks] = __builtin_bit_cast(bf16x8, a);
       gf[qt][ks] = __builtin_bit_cast(bf16x8, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dsum += __uint_as_float(o[e] << 16) * __uint_as_float(g[e] << 16);
+        dsum += __uint_as_float(o[e] & 0xffff0000u) * __uint_as_float(g[e] & 0xffff0000u);
+      }
     }
+    dsum = adm_quarter_sum(dsum);
     const long long si = ((long long)n * p.heads + hd) * p.T + (ok ? q : 0);
     lse[qt] = ok ? p.lse[si] : 0.f;
-    dl[qt] = ok ? p.delta[si] : 0.f;
+    dl[qt] = dsum;
+    if (ok && lq == 0) p.delta_out[si] = dsum;
   }
   f32x4 acc[DT][2];
 #pragma unroll
@@ -95,8 +84,8 @@ attn_dq_kernel(const AttnBwdK p) {
     for (int qt = 0; qt < 2; ++qt) acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   AdmTileRegs<TT, D, 256> kr, vr;
-  kr.load(base, p.C3, kcol, 0, p.T, tid);
-  vr.load(base, p.C3, vcol, 0, p.T, tid);
+  kr.load_buf(rs, p.C3, kcol, 0, tid);
+  vr.load_buf(rs, p.C3, vcol, 0, tid);
   kr.store(Ks[0], KROW, tid);
   vr.store(Vs[0], KROW, tid);
   __syncthreads();
@@ -106,8 +95,8 @@ attn_dq_kernel(const AttnBwdK p) {
     const int k0 = t0 * TT, cur = t0 & 1;
     const bool next = t0 + 1 < ntiles;
     if (next) {
-      kr.load(base, p.C3, kcol, k0 + TT, p.T, tid);
-      vr.load(base, p.C3, vcol, k0 + TT, p.T, tid);
+      kr.load_buf(rs, p.C3, kcol, k0 + TT, tid);
+      vr.load_buf(rs, p.C3, vcol, k0 + TT, tid);
     }
     const uint16_t* Kc = Ks[cur];
     const uint16_t* Vc = Vs[cur];
@@ -115,33 +104,39 @@ attn_dq_kernel(const AttnBwdK p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x4 st[2][2], dp[2][2];  // [key tile within the 32-key block][query tile]
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int kt = 2 * kb + kk;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) { st[kk][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kk][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            st[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], st[kk][qt], 0, 0, 0);
-            dp[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[qt][ks], dp[kk][qt], 0, 0, 0);
+            st[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? zero4 : st[kk][qt], 0, 0, 0);
+            dp[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[qt][ks], ks == 0 ? zero4 : dp[kk][qt], 0, 0, 0);
           }
         }
       }
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
+        // P = exp2(S c - lse), dS = P (dP - delta): packed fp32 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32)
+        const adm_f32x2 sc2 = {p.scale_log2, p.scale_log2}, nl2 = {-lse[qt], -lse[qt]}, nd2 = {-dl[qt], -dl[qt]};
+        float dsv[8];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const adm_f32x2 a = __builtin_elementwise_fma(adm_f32x2{st[kk][qt][2 * h], st[kk][qt][2 * h + 1]}, sc2, nl2);
+            const adm_f32x2 pr = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+            const adm_f32x2 d2 = pr * (adm_f32x2{dp[kk][qt][2 * h], dp[kk][qt][2 * h + 1]} + nd2);
+            dsv[kk * 4 + 2 * h] = d2.x;
+            dsv[kk * 4 + 2 * h + 1] = d2.y;
+          }
         bf16x8 f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int kk = e >> 2, r = e & 3;
-          const int key = k0 + (2 * kb + kk) * 16 + lq * 4 + r;
-          float pr = __builtin_amdgcn_exp2f(st[kk][qt][r] * p.scale_log2 - lse[qt]);
-          if (key >= p.T) pr = 0.f;
-          f[e] = (__bf16)(pr * (dp[kk][qt][r] - dl[qt]));
-        }
+        for (int e = 0; e < 8; ++e) f[e] = (__bf16)dsv[e];
         dsf[qt][kb] = f;
       }
     }
@@ -183,7 +178,7 @@ attn_dkv_kernel(const AttnBwdK p) {
   constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE;
   __shared__ __attribute__((aligned(16))) uint16_t Qs[2][TT * KROW];
   __shared__ __attribute__((aligned(16))) uint16_t Gs[2][TT * KROW];
-  __shared__ float lse_s[2][TT], dl_s[2][TT];
+  __shared__ __attribute__((aligned(16))) float lse_s[2][TT], dl_s[2][TT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
   const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
   const int kbase = blockIdx.x * BB + wave * BW;
@@ -192,6 +187,8 @@ attn_dkv_kernel(const AttnBwdK p) {
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;
   const long long sbase = ((long long)n * p.heads + hd) * p.T;
 
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, p.T * p.C * 2, 0x00020000);
   // K^T / V^T B-operand fragments of this wave's 32 keys: lane (key lc, quarter lq) holds row[key][ks*32 + 8*lq ..]
   bf16x8 kf[2][KS], vf[2][KS];
 #pragma unroll
@@ -199,11 +196,8 @@ attn_dkv_kernel(const AttnBwdK p) {
     const int key = kbase + kt * 16 + lc;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-      if (key < p.T) {
-        a = *reinterpret_cast<const uint4*>(base + (long long)key * p.C3 + kcol + ks * 32 + lq * 8);
-        b = *reinterpret_cast<const uint4*>(base + (long long)key * p.C3 + vcol + ks * 32 + lq * 8);
-      }
+      const adm_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (key * p.C3 + kcol + ks * 32 + lq * 8) * 2, 0, 0);
+      const adm_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (key * p.C3 + vcol + ks * 32 + lq * 8) * 2, 0, 0);
       kf[kt][ks] = __builtin_bit_cast(bf16x8, a);
       vf[kt][ks] = __builtin_bit_cast(bf16x8, b);
     }
@@ -217,11 +211,12 @@ attn_dkv_kernel(const AttnBwdK p) {
   AdmTileRegs<TT, D, 256> qr, gr;
   float lse_r = 0.f, dl_r = 0.f;
   auto load_rows = [&](int q0) {
-    qr.load(base, p.C3, qcol, q0, p.T, tid);
-    gr.load(dbase, p.C, hd * D, q0, p.T, tid);
+    qr.load_buf(rs, p.C3, qcol, q0, tid);
+    gr.load_buf(rsg, p.C, hd * D, q0, tid);
     if (tid < TT) {
+      // a query beyond T gets lse = +huge: its P = exp2(S c - lse) is exactly 0, no masking in the loop
       const int q = q0 + tid;
-      lse_r = q < p.T ? p.lse[sbase + q] : 0.f;
+      lse_r = q < p.T ? p.lse[sbase + q] : 1e30f;
       dl_r = q < p.T ? p.delta[sbase + q] : 0.f;
     }
   };
@@ -247,28 +242,34 @@ attn_dkv_kernel(const AttnBwdK p) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         f32x4 st[2], dp[2];              // the block's two 16-query tiles
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
           const int qt = 2 * qb + qq;
-          st[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
             const bf16x8 ga = *reinterpret_cast<const bf16x8*>(&Gc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-            st[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], st[qq], 0, 0, 0);
-            dp[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[kt][ks], dp[qq], 0, 0, 0);
+            st[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], ks == 0 ? zero4 : st[qq], 0, 0, 0);
+            dp[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[kt][ks], ks == 0 ? zero4 : dp[qq], 0, 0, 0);
           }
         }
+        // the 4 query rows of a lane quarter are consecutive: one 16-byte LDS read each for lse and delta
         bf16x8 f, g;
+        const adm_f32x2 sc2 = {p.scale_log2, p.scale_log2};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int qq = e >> 2, r = e & 3;
-          const int ql = (2 * qb + qq) * 16 + lq * 4 + r;  // query row within the tile
-          float pr = __builtin_amdgcn_exp2f(st[qq][r] * p.scale_log2 - lse_s[cur][ql]);
-          if (q0 + ql >= p.T) pr = 0.f;
-          f[e] = (__bf16)pr;
-          g[e] = (__bf16)(pr * (dp[qq][r] - dl_s[cur][ql]));
+        for (int qq = 0; qq < 2; ++qq) {
+          const int ql = (2 * qb + qq) * 16 + lq * 4;  // first query row of this lane within the tile
+          const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[cur][ql]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&dl_s[cur][ql]);
+          const adm_f32x2 a0 = __builtin_elementwise_fma(adm_f32x2{st[qq][0], st[qq][1]}, sc2, adm_f32x2{-l4.x, -l4.y});
+          const adm_f32x2 a1 = __builtin_elementwise_fma(adm_f32x2{st[qq][2], st[qq][3]}, sc2, adm_f32x2{-l4.z, -l4.w});
+          const adm_f32x2 p0 = {__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)};
+          const adm_f32x2 p1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
+          const adm_f32x2 s0 = p0 * (adm_f32x2{dp[qq][0], dp[qq][1]} - adm_f32x2{d4.x, d4.y});
+          const adm_f32x2 s1 = p1 * (adm_f32x2{dp[qq][2], dp[qq][3]} - adm_f32x2{d4.z, d4.w});
+          f[qq * 4 + 0] = (__bf16)p0.x; f[qq * 4 + 1] = (__bf16)p0.y; f[qq * 4 + 2] = (__bf16)p1.x; f[qq * 4 + 3] = (__bf16)p1.y;
+          g[qq * 4 + 0] = (__bf16)s0.x; g[qq * 4 + 1] = (__bf16)s0.y; g[qq * 4 + 2] = (__bf16)s1.x; g[qq * 4 + 3] = (__bf16)s1.y;
         }
         pf[kt] = f;
         dsf[kt] = g;
@@ -319,17 +320,13 @@ extern "C" int adm_attention_bwd(const adm_bf16* qkv, const adm_bf16* out, const
               "adm_attention_bwd: unaligned pointer");
   ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention_bwd: n*heads exceeds grid.y");
   AttnBwdK k{};
-  k.qkv = qkv; k.out = out; k.dout = dout; k.lse = lse; k.delta = delta_ws; k.dqkv = dqkv;
+  k.qkv = qkv; k.out = out; k.dout = dout; k.lse = lse; k.delta = delta_ws; k.delta_out = delta_ws; k.dqkv = dqkv;
   k.T = t; k.heads = heads; k.C = heads * d; k.C3 = 3 * k.C;
   if (new_order) { k.q_off = 0; k.k_off = k.C; k.v_off = 2 * k.C; k.head_stride = d; }
   else           { k.q_off = 0; k.k_off = d;   k.v_off = 2 * d;   k.head_stride = 3 * d; }
   k.inv_sqrt_d = 1.0f / sqrtf((float)d);
   k.scale_log2 = 1.4426950408889634f * k.inv_sqrt_d;
   hipStream_t s = (hipStream_t)stream;
-  const long long items = (long long)n * t * heads;
-  int blocks = (int)((items + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(delta_kernel, dim3(blocks), dim3(256), 0, s, out, dout, delta_ws, n, t, heads, d);
   dim3 grid((t + BB - 1) / BB, n * heads);
   if (d == 32) {
     hipLaunchKernelGGL((attn_dq_kernel<32>), grid, dim3(256), 0, s, k);

@@ -3,6 +3,8 @@
 #include "adm_common.h"
 
 typedef __attribute__((ext_vector_type(4))) short adm_s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int adm_u32x4;
+typedef __attribute__((ext_vector_type(2))) float adm_f32x2;
 
 // MFMA A-operand fragment (16 rows x 32 k, bf16) of the TRANSPOSE of a row-major LDS tile, read with the
 // hardware transposing load ds_read_b64_tr_b16: lane (lc = l & 15, lq = l >> 4) receives
@@ -34,6 +36,18 @@ struct AdmTileRegs {
       uint4 x = make_uint4(0, 0, 0, 0);
       if (u < UNITS && r0 + r < rmax) x = *reinterpret_cast<const uint4*>(base + (long long)(r0 + r) * row_stride + col0 + sg * 8);
       v[i] = x;
+    }
+  }
+  // the same through a buffer descriptor over the rows that exist (num_records = rmax * row_stride * 2 bytes from
+  // `base`): rows beyond it read as hardware zeros, so the loop carries no bounds branches
+  __device__ __forceinline__ void load_buf(__amdgpu_buffer_rsrc_t rs, int row_stride, int col0, int r0, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * NT;
+      const int r = u / (D / 8), sg = u % (D / 8);
+      const unsigned off = u < UNITS ? (unsigned)((r0 + r) * row_stride + col0 + sg * 8) * 2u : 0x80000000u;
+      const adm_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+      v[i] = make_uint4(x[0], x[1], x[2], x[3]);
     }
   }
   __device__ __forceinline__ void store(uint16_t* tile, int krow, int tid) const {
