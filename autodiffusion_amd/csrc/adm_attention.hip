@@ -211,6 +211,107 @@ attn_kernel(const AttnK p) {
   }
 }
 
+// ---- wide heads (D = 192, 256: ADM-128's num_heads = 4 gives 128 / 192 / 256 channels per head).  Same
+// formulation, sized for the register file instead of for speed: 16 queries per wave (64 per block), 32-key tiles
+// single-buffered in LDS, K / V^T fragments streamed one tile at a time.  Not on the benchmarked path.
+template <int D>
+__global__ void __launch_bounds__(256)
+attn_wide_kernel(const AttnK p) {
+  constexpr int KT2 = 32, QB2 = 64;
+  constexpr int KS = D / 32, DT = D / 16, KROW = D + PADE;
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[KT2 * KROW];
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[KT2 * KROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
+  const int q = blockIdx.x * QB2 + wave * 16 + lc;
+  const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
+  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
+            vcol = p.v_off + hd * p.head_stride;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+  f32x4 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  AdmTileRegs<KT2, D, 256> kr, vr;
+  const int ntiles = (p.T + KT2 - 1) / KT2;
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int k0 = kt0 * KT2;
+    kr.load_buf(rs, p.C3, kcol, k0, tid);
+    vr.load_buf(rs, p.C3, vcol, k0, tid);
+    __syncthreads();  // the previous tile's readers are done
+    kr.store(Ks, KROW, tid);
+    vr.store(Vs, KROW, tid);
+    __syncthreads();
+    // S^T = K . Q^T: 2 key tiles x 1 query tile
+    f32x4 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[kt], 0, 0, 0);
+      }
+    }
+    if (k0 + KT2 > p.T) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (k0 + kt * 16 + lq * 4 + r >= p.T) st[kt][r] = -1e30f;
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+    mx = adm_quarter_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+    const float mneg = -m_new * p.scale_log2;
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(st[kt][r] * p.scale_log2 + mneg);
+        psum += e;
+        pf[kt * 4 + r] = (__bf16)e;
+      }
+    l_run = l_run * alpha + psum;
+    // O^T += V^T . P^T; contraction slot k = 8*lq + e <-> key 16*(e>>2) + 4*lq + (e&3)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const bf16x8 vf = adm_tr_frag(Vs, KROW, 0, dt * 16, lc, lq);
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt] * alpha, 0, 0, 0);
+    }
+  }
+  const float l = adm_quarter_sum(l_run);
+  const float inv = 1.0f / l;
+  if (q >= p.T) return;
+  if (p.lse && lq == 0) p.lse[((long long)n * p.heads + hd) * p.T + q] = m_run * p.scale_log2 + log2f(l);
+  uint16_t* orow = p.out + ((long long)n * p.T + q) * p.C + hd * D;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const f32x4 o = oacc[dt] * inv;
+    uint2 pk;
+    pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
+    pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+    *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
+  }
+}
+
 }  // namespace
 
 extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int t, int heads, int d,
@@ -225,7 +326,8 @@ extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse,
                                  int new_order, void* stream) {
   ADM_REQUIRE(qkv && out, ADM_E_ARG, "adm_attention: null pointer");
   ADM_REQUIRE(n > 0 && t > 0 && heads > 0, ADM_E_ARG, "adm_attention: bad shape n=%d t=%d heads=%d", n, t, heads);
-  ADM_REQUIRE(d == 32 || d == 64 || d == 128, ADM_E_SHAPE, "adm_attention: head dim %d unsupported (32, 64, 128)", d);
+  ADM_REQUIRE(d == 32 || d == 64 || d == 128 || d == 192 || d == 256, ADM_E_SHAPE,
+              "adm_attention: head dim %d unsupported (32, 64, 128, 192, 256)", d);
   ADM_REQUIRE(adm_aligned16(qkv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention: unaligned pointer");
   ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention: n*heads exceeds grid.y");
   AttnK k{};
@@ -236,6 +338,12 @@ extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse,
   k.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
   dim3 grid((t + QB - 1) / QB, n * heads);
   hipStream_t s = (hipStream_t)stream;
+  if (d > 128) {
+    dim3 gridw((t + 63) / 64, n * heads);
+    if (d == 192) hipLaunchKernelGGL((attn_wide_kernel<192>), gridw, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((attn_wide_kernel<256>), gridw, dim3(256), 0, s, k);
+    return adm_check_launch("adm_attention");
+  }
   if (d == 32) hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, k);
   else if (d == 64) hipLaunchKernelGGL((attn_kernel<64>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, k);

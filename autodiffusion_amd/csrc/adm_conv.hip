@@ -40,6 +40,9 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+#ifndef ADM_CONV_RD
+#define ADM_CONV_RD 2    // 1x1: activation stages in flight (register ring)
+#endif
 #ifndef ADM_CONV_KS2
 #define ADM_CONV_KS2 0   // 1: 1x1 convs use 64-channel stages where the channel counts allow
 #endif
@@ -378,7 +381,7 @@ conv_kernel(const ConvK p) {
   // from) go out once the accumulators' registers are free.
   constexpr int WRING = TAPS == 9 ? 3 : (KS == 1 ? 4 : 2 * KS);
   uint4 wr[WRING][TN];
-  uint4 ring[2][PASSES];
+  uint4 ring[ADM_CONV_RD][PASSES];
   float4 bs[TN];
   const int last = chunks - 1;
   auto first_loads = [&](int lq_) {
@@ -396,6 +399,10 @@ conv_kernel(const ConvK p) {
       }
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(1, last), ps);
+#if ADM_CONV_RD == 3
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps) ring[2][ps] = halo_load(min(2, last), ps);
+#endif
     }
     // bias fragment (whole float4 or nothing: a ragged last fragment only exists with the fp32 NCHW output,
     // which adds those channels' bias at the store)
@@ -480,6 +487,28 @@ conv_kernel(const ConvK p) {
       // MFMAs of stage c against transform + park of stage c+1 -- shortened this loop: ~1 us per K-step either way.)
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+#if ADM_CONV_RD == 3
+      if constexpr (KS == 1) {
+        // experiment: three activation stages in flight, weights two K-steps ahead (rings of 3, unrolled by 3)
+        auto body = [&](int c, auto s_) {
+          constexpr int S = decltype(s_)::value;
+          if (c > last) return;
+          affine_park(affine_load(min(c + 2, last), img0), c & 1);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) ring[S][ps] = halo_load(min(c + 3, last), ps);
+          load_w(min(c + 2, last), wr[(S + 2) % 3]);
+          mfma_tap(halo + (c & 1) * Lds::HB, wr[S]);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[(S + 1) % 3][ps], ps, (c + 1) & 1);
+          __syncthreads();
+        };
+        for (int c0 = 0; c0 < chunks; c0 += 3) {
+          body(c0, I0{});
+          body(c0 + 1, I1{});
+          body(c0 + 2, I2{});
+        }
+      } else
+#endif
       if constexpr (KS == 1) {
         auto body = [&](int c, auto sa_, auto sw_) {
           constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;

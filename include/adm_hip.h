@@ -173,7 +173,7 @@ int adm_pack_conv_weight(const float* w, adm_bf16* out, int cout, int cin, int t
  * qkv bf16 [N][T][3*H*D] (token-major, the 1x1 qkv conv's NHWC output) -> out bf16 [N][T][H*D];
  * softmax in fp32 over all T keys, logits scaled by 1/sqrt(D) (= the reference's
  * ch^-1/4 on q and on k).  new_order 1: channels are [3][H][D]; 0 (legacy): [H][3][D].
- * D in {32, 64, 128}.                                                                     */
+ * D in {32, 64, 128} (tuned path) or {192, 256} (ADM-128's fixed head count: sized to fit, not tuned). */
 int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, int d,
                   int new_order, void* stream);
 

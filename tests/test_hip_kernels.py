@@ -224,7 +224,8 @@ def test_conv_rejects_bad_shapes(ops):
 
 # ------------------------------------------------------------------ attention (K5)
 @pytest.mark.parametrize("n,heads,d,t", [(2, 2, 32, 64), (2, 1, 64, 256), (1, 6, 64, 1024), (3, 2, 32, 16),
-                                         (1, 2, 64, 80), (2, 4, 128, 256)])
+                                         (1, 2, 64, 80), (2, 4, 128, 256),
+                                         (1, 2, 192, 100), (2, 4, 256, 64), (1, 4, 192, 256)])  # ADM-128's wide heads
 @pytest.mark.parametrize("new_order", [True, False])
 def test_attention_matches_oracle(ops, n, heads, d, t, new_order):
     from oracle import nets

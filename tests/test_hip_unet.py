@@ -65,6 +65,28 @@ def test_unet_m64_golden_and_batch_independence():
     assert torch.equal(out5[:2], out) and torch.equal(out5[2:4], out) and torch.equal(out5[4], out[0])
 
 
+def test_unet_fixed_head_count_wide_heads_matches_oracle():
+    """ADM-128's attention configuration in miniature (`GD/configs/128_guided_sample.sh:1`: a fixed num_heads, legacy
+    qkv order, no num_head_channels), where the head width follows the channel count: here one head over 128 and
+    192 channels (ADM-128 itself: 128 / 192 / 256 per head).  The reference holds no fixture for this configuration,
+    so the golden-pinned oracle is the checker."""
+    from autodiffusion_amd.arch import build_unet_plan
+    from oracle import nets
+    plan = build_unet_plan(
+        image_size=32, in_channels=3, model_channels=64, out_channels=6, num_res_blocks=1,
+        attention_resolutions=(2, 4), channel_mult=(1, 2, 3), num_classes=1000,
+        num_heads=1, num_head_channels=-1, use_scale_shift_norm=True, resblock_updown=True,
+        use_new_attention_order=False, dynamic=False)
+    sd = filled(plan)
+    m = _model(plan)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 32, 32, generator=gen)
+    t = torch.tensor([37, 911])
+    y = torch.tensor([3, 998])
+    ref = nets.unet_forward({k: torch.from_numpy(v) for k, v in sd.items()}, plan, x, t, y)
+    check(m(x.to(DEV), t.to(DEV), y.to(DEV)), ref.numpy(), "wide heads (d = 128, 192)")
+
+
 def test_unet_requires_y_iff_class_cond_and_device_tensors():
     from autodiffusion_amd._lib import AdmError
     m = _model(plan_m32(dynamic=False))
