@@ -90,6 +90,43 @@ def test_full_size_adm64_properties():
     assert not torch.equal(a, ev.sample_batch(5, seed=12))
 
 
+@pytest.mark.parametrize("name", ["adm128", "lsun256"])
+def test_full_size_other_reference_configs(name):
+    """The other architectures SURVEY 8(d) lists -- ADM-G ImageNet-128 (`GD/configs/128_guided_sample.sh:1`: 256
+    channels, (1,1,2,3,4), num_heads 4 => 128/192/256-wide heads, legacy qkv order) and ADM LSUN-256
+    (`GD/search_lsun_cat.sh:1`: 256 channels, (1,1,2,2,4,4), 64-wide heads, legacy order, dynamic) -- build through the
+    reference factory signature and run: finite, deterministic, batch-slice invariant (size-independent properties;
+    no checkpoint is reachable offline)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from autodiffusion_amd.script_util import create_model_and_diffusion, model_and_diffusion_defaults
+    flags = model_and_diffusion_defaults()
+    if name == "adm128":
+        flags.update(image_size=128, class_cond=True, learn_sigma=True, num_channels=256, num_res_blocks=2, num_heads=4,
+                     attention_resolutions="32,16,8", resblock_updown=True, use_scale_shift_norm=True, use_fp16=True,
+                     diffusion_steps=1000, noise_schedule="linear")
+        size, n = 128, 3
+    else:
+        flags.update(image_size=256, class_cond=False, learn_sigma=True, num_channels=256, num_res_blocks=2,
+                     num_head_channels=64, attention_resolutions="32,16,8", resblock_updown=True,
+                     use_scale_shift_norm=True, use_fp16=True, diffusion_steps=1000, noise_schedule="linear",
+                     use_dynamic_unet=True)
+        size, n = 256, 2
+    model, diffusion = create_model_and_diffusion(**flags)
+    model.to(DEV).randomize_(9)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, 3, size, size, generator=g).to(DEV)
+    t = torch.tensor([500] * n, device=DEV)
+    y = torch.randint(0, 1000, (n,), generator=g).to(DEV) if name == "adm128" else None
+    out = model(x, t, y)
+    assert out.shape == (n, 6, size, size) and torch.isfinite(out).all() and float(out.std()) > 1e-3
+    assert torch.equal(model(x, t, y), out)
+    assert torch.equal(model(x[:1], t[:1], None if y is None else y[:1]), out[:1])
+    if name == "lsun256":
+        sk = model(x, t, y, skip_layer=[1, 5, model.layer_num - 2])
+        assert torch.isfinite(sk).all() and not torch.equal(sk, out)
+
+
 def test_sampling_cli_writes_the_reference_npz_format(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
