@@ -484,7 +484,9 @@ conv_kernel(const ConvK p) {
       // The loop is unrolled so that every ring slot is a compile-time register; indices past the last stage are
       // clamped (harmless re-reads).
       // (Measured, MI355X: neither 64-channel stages nor running the two waves of a SIMD in opposite phases --
-      // MFMAs of stage c against transform + park of stage c+1 -- shortened this loop: ~1 us per K-step either way.)
+      // MFMAs of stage c against transform + park of stage c+1 -- shortened this loop: ~1 us per K-step either way.
+      // Ablations on the timing build: without the transform + park the GN-prologue loop is 43 % shorter, without
+      // the activation loads the raw loop is 48 % shorter; weights and the barrier are not the limit.)
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 #if ADM_CONV_RD == 3
@@ -523,6 +525,9 @@ conv_kernel(const ConvK p) {
           for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
           __syncthreads();
         };
+        // (Peeling the tail so that the unrolled group has no early exit removes the s_waitcnt vmcnt(0) hipcc puts
+        // at the loop header, but the 192-wide GN-prologue instantiation then spills inside the loop: 530 -> 690 us
+        // on qkv 384->1152 @32^2; the 128-wide tile, which does not spill, gained 3 %.)
         for (int c0 = 0; c0 < chunks; c0 += 4) {
           body(c0, I0{}, I0{});
           body(c0 + 1, I1{}, I1{});
