@@ -57,6 +57,7 @@ SIGNATURES = {
     "adm_resample": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_conv": (_I, [C.POINTER(ConvArgs), _P]),
     "adm_conv_stat_slabs": (_I, [C.POINTER(ConvArgs)]),
+    "adm_conv_pick_variant": (_I, [C.POINTER(ConvArgs)]),
     "adm_gn_finalize2": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P]),
     "adm_packed_weight_elems": (C.c_int64, [_I, _I, _I]),
     "adm_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "adm_common.h"
+#include "adm_conv_internal.h"
 
 namespace {
 
@@ -1179,7 +1180,14 @@ extern "C" int adm_pack_conv_weight32(const float* w, adm_bf16* out, int cout, i
 
 extern "C" int adm_conv_stat_slabs(const adm_conv_args* a) {
   if (!a) return 0;
+  if (const int bm = adm_conv1x1_resident_bm(a)) return a->h * a->w / bm;
   return stat_slabs_for(a, pick_variant(a));
+}
+
+extern "C" int adm_conv_pick_variant(const adm_conv_args* a) {
+  if (!a) return 0;
+  if (adm_conv1x1_resident_bm(a)) return 10;
+  return pick_variant(a);
 }
 
 extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
@@ -1199,6 +1207,10 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
               adm_aligned16(a->aff_a) && adm_aligned16(a->aff_b) && adm_aligned16(a->bias) &&
               adm_aligned16(a->res) && adm_aligned16(a->out), ADM_E_ALIGN, "adm_conv: unaligned pointer");
   ADM_REQUIRE((long long)a->n * a->h * a->w < (1ll << 31) / 4, ADM_E_SHAPE, "adm_conv: too many pixels for 32-bit index");
+
+  // 1x1 with the activation tile resident in LDS across all Cout blocks (adm_conv1x1.hip)
+  if (const int bm = adm_conv1x1_resident_bm(a)) return adm_conv1x1_resident_launch(a, bm, stream);
+  ADM_REQUIRE(a->variant != 10, ADM_E_SHAPE, "adm_conv: variant 10 (resident-tile 1x1) does not take this shape");
 
   ConvK k{};
   k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;

@@ -1,0 +1,321 @@
+// 1x1 convolutions with the activation tile RESIDENT in LDS (gfx950).  Part of adm_conv (adm_conv.hip dispatches
+// here); same operands, weight packing and epilogue contract.
+//
+// Replaces the reference's Conv1d qkv / proj_out of AttentionBlock._forward (guided_diffusion/unet.py:299-305) and
+// the 1x1 skip_connection of ResBlock (unet.py:225-231, 256) -- with the preceding GroupNorm folded in as a
+// per-(image, channel) affine, the residual add and the next GroupNorm's partial sums in the epilogue.
+//
+// Why a second kernel: in the staged kernel (conv_kernel<..., TAPS = 1>) a 32-channel K-step is one barrier interval
+// that has to fetch, transform and park 16 KB of new activations for only 24 MFMAs per wave -- ablations on MI355X
+// show the GN-prologue loop 43 % shorter without the transform + park and the raw loop 48 % shorter without the
+// activation loads -- and every Cout block repeats that work.  Here a block owns BM pixels x ALL input channels:
+// the tile is fetched and transformed ONCE, stays in LDS (row = 2K + 32 bytes: conflict-free ds_read_b128
+// fragments for K % 64 == 0), and the block then walks every 384-wide Cout block with a K loop that has no
+// barrier, no global activation traffic and no VALU work: per K-step and wave 8 (BM = 128) LDS fragment reads,
+// 3 weight-fragment loads (fragment-ordered, L2-resident, register ring 3 K-steps ahead) and 24 MFMAs.
+//   waves      8 = 1 x 8: a wave owns all BM pixels x 48 output channels (TN = 3), the block BM x 384
+//   epilogue   per Cout block, in two halves of 192 channels: accumulators (started from the bias) -> bf16 -> LDS
+//              -> coalesced 16-byte row stores with the residual and the output's GroupNorm partial sums
+//   launch     persistent over pixel tiles (flattened N*H*W; BM <= H*W, so a tile lies in one image)
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "adm_common.h"
+#include "adm_conv_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned OOB = 0x80000000u;
+
+struct Conv1K {
+  const uint16_t* in0; const uint16_t* in1; const uint16_t* w; const uint16_t* res;
+  const float* bias; const float* aa; const float* ab; uint16_t* out; float* stats;
+  int N, HW, C0, C1, Cout, ntiles16, stat_slabs, m_tiles, nblocks_n;
+  unsigned wbytes, rcp_seg;   // rcp_seg = ceil(2^32 / (K/8)): idx / (K/8) == umulhi(idx, rcp_seg)
+};
+
+__device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <int BM>
+constexpr int c1_stg_bytes() { return BM * (192 * 2 + 16) > (512 / 24) * 192 * 8 ? BM * (192 * 2 + 16) : (512 / 24) * 192 * 8; }
+template <int BM>
+constexpr int c1_lds_bytes(int k) { return BM * (2 * k + 32) + c1_stg_bytes<BM>() + 2 * k * 4; }
+
+template <int BM, int PRO>
+__global__ void __launch_bounds__(512, 2)
+conv1x1r_kernel(const Conv1K p) {
+  constexpr int NT = 512, TM = BM / 16, TN = 3, BNH = 192;   // BNH: channels per epilogue half (4 waves x 48)
+  constexpr int EROW = BNH * 2 + 16, SEGS = BNH / 8, PR = NT / SEGS, NIT = (BM + PR - 1) / PR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = p.C0 + p.C1, RB = 2 * K + 32, ksteps = K / 32, segk = K / 8;
+  unsigned char* const A = smem;                              // [BM][RB]
+  unsigned char* const stg = smem + BM * RB;                  // [BM][EROW]; also the statistics reduction
+  float* const tab = reinterpret_cast<float*>(stg + c1_stg_bytes<BM>());  // a[K] | b[K] of the tile's image
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.Cout * 4, 0x00020000);
+  const unsigned wstep = (unsigned)p.ntiles16 * 1024u;
+
+  // XCD-aware static tile list (see conv_kernel): XCD x owns a contiguous run of pixel tiles
+  const int xcd = blockIdx.x & 7;
+  const int gx = (int)(gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7));
+  const int tcount = (p.m_tiles >> 3) + (xcd < (p.m_tiles & 7));
+  const int tstart = xcd * (p.m_tiles >> 3) + min(xcd, p.m_tiles & 7);
+
+  for (int tl = blockIdx.x >> 3; tl < tcount; tl += gx) {
+    const int pb = (tstart + tl) * BM;           // first pixel of the tile in the flattened [N*H*W] order
+    const int img = pb / p.HW;
+    __syncthreads();                             // the previous tile's readers of A / tab / stg are done
+    // ---- affine table of this image, then the activation tile: fetched, transformed, parked -- once
+    if constexpr (PRO != 0) {
+      for (int i = tid; i < 2 * K / 4; i += NT) {
+        const int half = i >= K / 4, j = half ? i - K / 4 : i;
+        *reinterpret_cast<float4*>(tab + half * K + j * 4) =
+            *reinterpret_cast<const float4*>((half ? p.ab : p.aa) + (long long)img * K + j * 4);
+      }
+      __syncthreads();
+    }
+    for (int i0 = 0; i0 < BM * segk; i0 += 4 * NT) {
+      uint4 v[4];
+      int px[4], sg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * NT + tid;
+        px[u] = (int)__umulhi((unsigned)idx, p.rcp_seg);
+        sg[u] = idx - px[u] * segk;
+        v[u] = make_uint4(0, 0, 0, 0);
+        if (px[u] < BM) {
+          const int ch = sg[u] * 8;
+          const long long pix = (long long)pb + px[u];
+          v[u] = ch < p.C0 ? *reinterpret_cast<const uint4*>(p.in0 + pix * p.C0 + ch)
+                           : *reinterpret_cast<const uint4*>(p.in1 + pix * p.C1 + (ch - p.C0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (px[u] >= BM) continue;
+        uint4 o = v[u];
+        if constexpr (PRO != 0) {
+          const float* ta = tab + sg[u] * 8;
+          float a8[8], b8[8];
+          *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ta);
+          *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ta + 4);
+          *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ta + K);
+          *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ta + K + 4);
+          uint32_t w4[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float lo = __uint_as_float(w4[j] << 16), hi = __uint_as_float(w4[j] & 0xffff0000u);
+            lo = a8[2 * j] * lo + b8[2 * j];
+            hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
+            if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
+            w4[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+          }
+          o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        *reinterpret_cast<uint4*>(A + px[u] * RB + sg[u] * 16) = o;
+      }
+    }
+    __syncthreads();
+
+    const unsigned char* const alane = A + lc * RB + lq * 16;  // fragment row of this lane inside a 16-pixel tile
+    for (int nb = 0; nb < p.nblocks_n; ++nb) {
+      // ---- K loop over the resident tile: no barrier, no global activation traffic
+      unsigned wofs[TN];
+      f32x4 acc[TM][TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int t16 = nb * 24 + wave * TN + j;
+        wofs[j] = t16 < p.ntiles16 ? (unsigned)((t16 * 64 + lane) * 16) : OOB;
+        const int bch = t16 * 16 + lq * 4;
+        const uint4 b = bufload16(rsb, bch + 3 < p.Cout ? (unsigned)bch * 4u : OOB, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[i][j] = f32x4{__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+      }
+      auto load_w = [&](int step, uint4 (&dst)[TN]) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) dst[j] = bufload16(rsw, wofs[j], (unsigned)step * wstep);
+      };
+      auto kstep = [&](int ks, const uint4 (&w)[TN]) {
+        bf16x8 af[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(alane + i * 16 * RB + ks * 64);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af[i], acc[i][j], 0, 0, 0);
+      };
+      uint4 wr[4][TN];
+      const int last = ksteps - 1;
+      load_w(0, wr[0]);
+      load_w(min(1, last), wr[1]);
+      load_w(min(2, last), wr[2]);
+      int k0 = 0;
+      for (; k0 + 3 <= last; k0 += 4) {  // whole groups of 4: no early exit inside the unrolled group
+        load_w(min(k0 + 3, last), wr[3]); kstep(k0, wr[0]);
+        load_w(min(k0 + 4, last), wr[0]); kstep(k0 + 1, wr[1]);
+        load_w(min(k0 + 5, last), wr[1]); kstep(k0 + 2, wr[2]);
+        load_w(min(k0 + 6, last), wr[2]); kstep(k0 + 3, wr[3]);
+      }
+      if (k0 <= last) kstep(k0, wr[0]);
+      if (k0 + 1 <= last) kstep(k0 + 1, wr[1]);
+      if (k0 + 2 <= last) kstep(k0 + 2, wr[2]);
+
+      // ---- epilogue, two halves of 192 channels (waves 0-3, then 4-7)
+      const int sgo = tid % SEGS, prow = tid / SEGS;
+#pragma unroll 1
+      for (int hf = 0; hf < 2; ++hf) {
+        const int cb = nb * 384 + hf * BNH;             // first output channel of this half
+        if (cb >= p.Cout) break;                        // block-uniform
+        __syncthreads();                                // staging buffer free
+        if ((wave >> 2) == hf) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int ch0 = ((wave & 3) * TN + j) * 16 + lq * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              uint2 o;
+              o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1]) << 16);
+              o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3]) << 16);
+              *reinterpret_cast<uint2*>(stg + (i * 16 + lc) * EROW + ch0 * 2) = o;
+            }
+          }
+        }
+        const int gch = cb + sgo * 8;
+        const bool act = prow < PR && gch < p.Cout;
+        uint4 rr[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int m = prow + k * PR;
+          rr[k] = make_uint4(0, 0, 0, 0);
+          if (p.res && act && m < BM) rr[k] = *reinterpret_cast<const uint4*>(p.res + ((long long)pb + m) * p.Cout + gch);
+        }
+        __syncthreads();
+        f32x2 s1[4], s2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] = f32x2{0.f, 0.f}; s2[q] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int m = prow + k * PR;
+          if (!act || m >= BM) continue;
+          uint4 v = *reinterpret_cast<const uint4*>(stg + m * EROW + sgo * 16);
+          uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+          if (p.res) {
+            const uint32_t r4[4] = {rr[k].x, rr[k].y, rr[k].z, rr[k].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)} +
+                              f32x2{__uint_as_float(r4[q] << 16), __uint_as_float(r4[q] & 0xffff0000u)};
+              a4[q] = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+            }
+            v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+          }
+          *reinterpret_cast<uint4*>(p.out + ((long long)pb + m) * p.Cout + gch) = v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)};
+            s1[q] += t;
+            s2[q] = __builtin_elementwise_fma(t, t, s2[q]);
+          }
+        }
+        if (p.stats) {
+          // reduce the PR row-partials of every channel through LDS (fixed order: bitwise reproducible)
+          float* red = reinterpret_cast<float*>(stg);  // [PR][BNH][2]
+          __syncthreads();
+          if (prow < PR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              red[(prow * BNH + sgo * 8 + e) * 2 + 0] = s1[e >> 1][e & 1];
+              red[(prow * BNH + sgo * 8 + e) * 2 + 1] = s2[e >> 1][e & 1];
+            }
+          }
+          __syncthreads();
+          if (tid < BNH && cb + tid < p.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int q = 0; q < PR; ++q) { t1 += red[(q * BNH + tid) * 2]; t2 += red[(q * BNH + tid) * 2 + 1]; }
+            const int slab = (pb - img * p.HW) / BM;
+            float* dst = p.stats + (((long long)img * p.stat_slabs + slab) * p.Cout + cb + tid) * 2;
+            dst[0] = t1;
+            dst[1] = t2;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int PRO>
+int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
+  static int slots_dev[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& slots = slots_dev[dev & 63];
+  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO>);
+  if (slots == 0) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv (1x1 resident): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int ncu = 0;
+    e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || ncu <= 0) ADM_FAIL((int)e, "adm_conv: hipDeviceGetAttribute: %s", hipGetErrorString(e));
+    slots = ncu;  // one block per CU: the resident tile takes most of the LDS
+  }
+  const unsigned blocks = (unsigned)(k.m_tiles < slots ? k.m_tiles : slots);
+  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO>), dim3(blocks), dim3(512), smem, s, k);
+  return adm_check_launch("adm_conv");
+}
+
+}  // namespace
+
+// pixels per resident tile (128 or 64) if these arguments can run on the resident-tile kernel, else 0
+int adm_conv1x1_resident_bm(const adm_conv_args* a) {
+  static const bool disabled = getenv("ADM_CONV_NO_RESIDENT") != nullptr;  // A/B switch for measurements
+  if (disabled && a->variant == 0) return 0;
+  if (a->taps != 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 10)) return 0;
+  const int k = a->c0 + a->c1, hw = a->h * a->w;
+  if (k % 64 != 0 || a->c0 % 8 != 0 || a->c1 % 8 != 0 || a->cout % 8 != 0 || hw % 64 != 0) return 0;
+  if (a->variant == 0 && a->cout < 256) return 0;   // narrow outputs: the 384-wide Cout block would idle half the waves
+  const int lim = 160 * 1024;
+  if (hw % 128 == 0 && c1_lds_bytes<128>(k) <= lim) return 128;
+  if (c1_lds_bytes<64>(k) <= lim) return 64;
+  return 0;
+}
+
+int adm_conv1x1_resident_launch(const adm_conv_args* a, int bm, void* stream) {
+  Conv1K k{};
+  k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;
+  k.bias = a->bias; k.aa = a->aff_a; k.ab = a->aff_b; k.out = (uint16_t*)a->out; k.stats = a->out_stats;
+  k.N = a->n; k.HW = a->h * a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
+  k.ntiles16 = (a->cout + 15) / 16;
+  k.stat_slabs = k.HW / bm;
+  k.m_tiles = (int)((long long)a->n * k.HW / bm);
+  k.nblocks_n = (a->cout + 383) / 384;
+  const int kk = a->c0 + a->c1;
+  k.wbytes = (unsigned)(((long long)kk / 32) * k.ntiles16 * 1024);
+  const unsigned segk = (unsigned)kk / 8;
+  k.rcp_seg = (unsigned)(((1ull << 32) + segk - 1) / segk);
+  hipStream_t s = (hipStream_t)stream;
+  const int smem = bm == 128 ? c1_lds_bytes<128>(kk) : c1_lds_bytes<64>(kk);
+  if (bm == 128) {
+    switch (a->prologue) {
+      case 0: return launch_c1<128, 0>(k, smem, s);
+      case 1: return launch_c1<128, 1>(k, smem, s);
+      default: return launch_c1<128, 2>(k, smem, s);
+    }
+  }
+  switch (a->prologue) {
+    case 0: return launch_c1<64, 0>(k, smem, s);
+    case 1: return launch_c1<64, 1>(k, smem, s);
+    default: return launch_c1<64, 2>(k, smem, s);
+  }
+}

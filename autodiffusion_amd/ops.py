@@ -26,14 +26,6 @@ USE_FUSED_STATS = True
 CONV_PROFILE = None
 
 
-def conv_variant(cout: int, hw: int) -> int:
-    """Tiling variant picked for an output-channel count and map size (mirrors adm_conv's auto rule)."""
-    if cout <= 16:
-        return 3
-    w192, w128 = -(-cout // 192) * 192, -(-cout // 128) * 128
-    return 5 if w192 <= w128 else 6
-
-
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -233,13 +225,13 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.res = _ptr(res, BF16, "res")
     a.out = _ptr(out)
     a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, c1, cout
+    a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
+    a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     if variant == 0:
-        variant = conv_variant(cout, h * w)
+        variant = _lib.load().adm_conv_pick_variant(C.byref(a))  # the library's own rule (incl. the resident-tile 1x1 kernel)
         if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw:
             variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
-    a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
-    a.variant = variant
-    a.taps, a.out_mode = taps, int(out_f32_nchw)
+        a.variant = variant
     fused = None
     if want_stats and USE_FUSED_STATS:
         slabs = _lib.load().adm_conv_stat_slabs(C.byref(a))
@@ -247,7 +239,6 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
             fused = (torch.empty((n, slabs, cout, 2), dtype=torch.float32, device=dev), slabs)
             a.out_stats = fused[0].data_ptr()
             out._adm_stats = fused
-    a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -148,7 +148,8 @@ typedef struct adm_conv_args {
   int32_t prologue;  /* 0,1,2  */
   int32_t out_mode;  /* 0,1    */
   int32_t variant;   /* tiling variant: 0 = auto (5 or 6 by least Cout padding, 3 for cout <= 16); 5 = 192-wide and
-                        6 = 128-wide 8-wave tiles; 3 = 16-wide (output head / stem backward); 7 = 32x32x16 MFMA kernel */
+                        6 = 128-wide 8-wave tiles; 3 = 16-wide (output head / stem backward); 7 = 32x32x16 MFMA kernel;
+                        10 = 1x1 with the activation tile resident in LDS (auto for 1x1, cin % 64 == 0, cout >= 256) */
   float* out_stats;  /* optional: fp32 [N][slabs][cout][2] = per-(image, slab, channel) sum and sum of squares of
                         the bf16 OUTPUT, accumulated in the epilogue (slabs = adm_conv_stat_slabs(args)); the
                         consumer's GroupNorm then needs no adm_gn_partial pass over the tensor */
@@ -159,6 +160,8 @@ typedef struct adm_conv_args {
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */
 int adm_conv_stat_slabs(const adm_conv_args* args_host);
+/* the tiling variant adm_conv will run for these arguments (resolves variant 0; 10 = resident-tile 1x1 kernel) */
+int adm_conv_pick_variant(const adm_conv_args* args_host);
 
 /* fp32 [cout, cin, kh, kw] (kh*kw = taps) -> bf16 fragment-ordered image
  * [cin/32][taps][ceil(cout/16)][64 lanes][8]; out must hold adm_packed_weight_elems().   */
