@@ -47,3 +47,10 @@ __device__ __forceinline__ float adm_silu(float v) {
   // IEEE division here would triple the VALU cost of the conv prologue, which shares issue slots with MFMA
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }
+// two at a time: the non-transcendental half of the work as packed fp32 (v_pk_mul_f32 / v_pk_add_f32)
+typedef float adm_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ adm_f32x2_t adm_silu2(adm_f32x2_t v) {
+  const adm_f32x2_t t = v * adm_f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+  const adm_f32x2_t d = adm_f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + adm_f32x2_t{1.0f, 1.0f};
+  return v * adm_f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}

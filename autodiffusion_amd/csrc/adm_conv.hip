@@ -327,11 +327,10 @@ conv_kernel(const ConvK p) {
       const bool valid = pixrel[ps] >= 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
-        lo = a8[2 * j] * lo + b8[2 * j];
-        hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
-        if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-        const uint32_t pk = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        adm_f32x2_t t = {__uint_as_float(u[j] << 16), __uint_as_float(u[j] & 0xffff0000u)};
+        t = __builtin_elementwise_fma(adm_f32x2_t{a8[2 * j], a8[2 * j + 1]}, t, adm_f32x2_t{b8[2 * j], b8[2 * j + 1]});
+        if constexpr (PRO == 2) t = adm_silu2(t);
+        const uint32_t pk = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
         u[j] = valid ? pk : 0u;
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
