@@ -146,15 +146,29 @@ conv1x1r_kernel(const Conv1K p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) dst[j] = bufload16(rsw, wofs[j], (unsigned)step * wstep);
       };
+      // LDS fragment reads run AFD pixel tiles ahead of the MFMAs that consume them, pinned in the emitted code
+      // (hipcc otherwise issues all reads, waits lgkmcnt(0), then the MFMAs: the read latency opens every K-step)
       auto kstep = [&](int ks, const uint4 (&w)[TN]) {
+        constexpr int AFD = TM < 4 ? TM : 4;
+        const unsigned char* ak = alane + ks * 64;
+        __builtin_amdgcn_sched_barrier(0);
         bf16x8 af[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(alane + i * 16 * RB + ks * 64);
+        for (int i = 0; i < AFD; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ak + i * 16 * RB);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+          if (i + AFD < TM) af[i + AFD] = *reinterpret_cast<const bf16x8*>(ak + (i + AFD) * 16 * RB);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af[i], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < AFD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (i + AFD < TM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+        }
       };
       uint4 wr[4][TN];
       const int last = ksteps - 1;
