@@ -14,8 +14,9 @@
 // barrier, no global activation traffic and no VALU work: per K-step and wave 8 (BM = 128) LDS fragment reads,
 // 3 weight-fragment loads (fragment-ordered, L2-resident, register ring 3 K-steps ahead) and 24 MFMAs.
 //   waves      8 = 1 x 8: a wave owns all BM pixels x 48 output channels (TN = 3), the block BM x 384
-//   epilogue   per Cout block, in two halves of 192 channels: accumulators (started from the bias) -> bf16 -> LDS
-//              -> coalesced 16-byte row stores with the residual and the output's GroupNorm partial sums
+//   epilogue   wave-private and barrier-free: accumulators (started from the bias) -> bf16 -> the wave's own 4 KB of
+//              LDS -> 16-byte row-segment stores with the residual and the output's GroupNorm partial sums; with
+//              no barrier in the Cout loop the waves drift apart and one wave's stores overlap another's MFMAs
 //   launch     persistent over pixel tiles (flattened N*H*W; BM <= H*W, so a tile lies in one image)
 #include <stdlib.h>
 
@@ -47,15 +48,17 @@ constexpr int c1_stg_bytes() { return BM * (192 * 2 + 16) > (512 / 24) * 192 * 8
 template <int BM>
 constexpr int c1_lds_bytes(int k) { return BM * (2 * k + 32) + c1_stg_bytes<BM>() + 2 * k * 4; }
 
-template <int BM, int PRO>
+// WP: wave-private barrier-free epilogue (outputs without a residual operand) or the block-wide two-half epilogue
+template <int BM, int PRO, bool WP>
 __global__ void __launch_bounds__(512, 2)
 conv1x1r_kernel(const Conv1K p) {
-  constexpr int NT = 512, TM = BM / 16, TN = 3, BNH = 192;   // BNH: channels per epilogue half (4 waves x 48)
+  constexpr int NT = 512, TM = BM / 16, TN = 3, BNH = 192;   // BNH: channels per block-epilogue half (4 waves x 48)
   constexpr int EROW = BNH * 2 + 16, SEGS = BNH / 8, PR = NT / SEGS, NIT = (BM + PR - 1) / PR;
+  constexpr int WROW = 112, WST = 4096;   // wave-private restage: 32 pixels x (96 + 16 pad) bytes, in 4 KB per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int K = p.C0 + p.C1, RB = 2 * K + 32, ksteps = K / 32, segk = K / 8;
   unsigned char* const A = smem;                              // [BM][RB]
-  unsigned char* const stg = smem + BM * RB;                  // [BM][EROW]; also the statistics reduction
+  unsigned char* const stg = smem + BM * RB;                  // 8 x WST: wave-private output restage / statistics
   float* const tab = reinterpret_cast<float*>(stg + c1_stg_bytes<BM>());  // a[K] | b[K] of the tile's image
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -186,6 +189,82 @@ conv1x1r_kernel(const Conv1K p) {
       if (k0 + 1 <= last) kstep(k0 + 1, wr[1]);
       if (k0 + 2 <= last) kstep(k0 + 2, wr[2]);
 
+      if constexpr (WP) {
+      // ---- epilogue, WAVE-PRIVATE and barrier-free: a wave owns all BM pixels of its 48 channels, so it restages
+      // its own accumulators (32 pixels at a time, bf16, 112-byte rows in its private 4 KB of LDS), reads them back
+      // as 16-byte row segments (6 per pixel, 10 pixels per wave-instruction) and stores them, adding the residual
+      // and accumulating the output's GroupNorm sums on the way.  LDS instructions of one wave execute in order, so
+      // the restage needs no barrier -- and with none anywhere in the Cout loop the 8 waves drift apart: one wave's
+      // stores overlap another's MFMAs (the layer is output-write bound at Cin = 384).
+      const int cbw = nb * 384 + wave * 48;             // first output channel of this wave
+      if (cbw < p.Cout) {                               // wave-uniform
+        unsigned char* const wst = stg + wave * WST;
+        const int sgl = lane % 6, rowl = lane / 6;      // lanes 0..59: segment sgl of pixel row rowl (+10 per step)
+        const bool lact = lane < 60 && cbw + sgl * 8 < p.Cout;
+        f32x2 s1[4], s2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] = f32x2{0.f, 0.f}; s2[q] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < TM / 2; ++c) {              // 32 pixels per round
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const f32x4 v = acc[2 * c + ii][j];
+              uint2 o;
+              o.x = (uint32_t)adm_f32_to_bf16(v[0]) | ((uint32_t)adm_f32_to_bf16(v[1]) << 16);
+              o.y = (uint32_t)adm_f32_to_bf16(v[2]) | ((uint32_t)adm_f32_to_bf16(v[3]) << 16);
+              *reinterpret_cast<uint2*>(wst + (ii * 16 + lc) * WROW + (j * 16 + lq * 4) * 2) = o;
+            }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {                 // rows rowl, +10, +20, +30 (< 32)
+            const int r = rowl + q * 10;
+            if (!lact || r >= 32) continue;
+            const long long eo = ((long long)pb + c * 32 + r) * p.Cout + cbw + sgl * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(wst + r * WROW + sgl * 16);
+            uint32_t a4[4] = {v.x, v.y, v.z, v.w};
+            if (p.res) {
+              const uint4 rr = *reinterpret_cast<const uint4*>(p.res + eo);
+              const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f32x2 t = f32x2{__uint_as_float(a4[e] << 16), __uint_as_float(a4[e] & 0xffff0000u)} +
+                                f32x2{__uint_as_float(r4[e] << 16), __uint_as_float(r4[e] & 0xffff0000u)};
+                a4[e] = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+              }
+              v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+            }
+            *reinterpret_cast<uint4*>(p.out + eo) = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 t = f32x2{__uint_as_float(a4[e] << 16), __uint_as_float(a4[e] & 0xffff0000u)};
+              s1[e] += t;
+              s2[e] = __builtin_elementwise_fma(t, t, s2[e]);
+            }
+          }
+        }
+        if (p.stats) {
+          // the 10 row-lanes of every channel segment, summed through the wave's private LDS in a fixed order
+          float* red = reinterpret_cast<float*>(wst);   // [10 rows][48 channels][2]
+          if (lane < 60) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              red[(rowl * 48 + sgl * 8 + e) * 2 + 0] = s1[e >> 1][e & 1];
+              red[(rowl * 48 + sgl * 8 + e) * 2 + 1] = s2[e >> 1][e & 1];
+            }
+          }
+          if (lane < 48 && cbw + lane < p.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) { t1 += red[(q * 48 + lane) * 2]; t2 += red[(q * 48 + lane) * 2 + 1]; }
+            const int slab = (pb - img * p.HW) / BM;
+            float* dst = p.stats + (((long long)img * p.stat_slabs + slab) * p.Cout + cbw + lane) * 2;
+            dst[0] = t1;
+            dst[1] = t2;
+          }
+        }
+      }
+      } else {
       // ---- epilogue, two halves of 192 channels (waves 0-3, then 4-7)
       const int sgo = tid % SEGS, prow = tid / SEGS;
 #pragma unroll 1
@@ -265,17 +344,18 @@ conv1x1r_kernel(const Conv1K p) {
           }
         }
       }
+      }
     }
   }
 }
 
-template <int BM, int PRO>
+template <int BM, int PRO, bool WP>
 int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
   static int slots_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   int& slots = slots_dev[dev & 63];
-  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO>);
+  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO, WP>);
   if (slots == 0) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv (1x1 resident): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -285,7 +365,7 @@ int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
     slots = ncu;  // one block per CU: the resident tile takes most of the LDS
   }
   const unsigned blocks = (unsigned)(k.m_tiles < slots ? k.m_tiles : slots);
-  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO>), dim3(blocks), dim3(512), smem, s, k);
+  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO, WP>), dim3(blocks), dim3(512), smem, s, k);
   return adm_check_launch("adm_conv");
 }
 
@@ -322,14 +402,14 @@ int adm_conv1x1_resident_launch(const adm_conv_args* a, int bm, void* stream) {
   const int smem = bm == 128 ? c1_lds_bytes<128>(kk) : c1_lds_bytes<64>(kk);
   if (bm == 128) {
     switch (a->prologue) {
-      case 0: return launch_c1<128, 0>(k, smem, s);
-      case 1: return launch_c1<128, 1>(k, smem, s);
-      default: return launch_c1<128, 2>(k, smem, s);
+      case 0: return (a->res ? launch_c1<128, 0, false>(k, smem, s) : launch_c1<128, 0, true>(k, smem, s));
+      case 1: return (a->res ? launch_c1<128, 1, false>(k, smem, s) : launch_c1<128, 1, true>(k, smem, s));
+      default: return (a->res ? launch_c1<128, 2, false>(k, smem, s) : launch_c1<128, 2, true>(k, smem, s));
     }
   }
   switch (a->prologue) {
-    case 0: return launch_c1<64, 0>(k, smem, s);
-    case 1: return launch_c1<64, 1>(k, smem, s);
-    default: return launch_c1<64, 2>(k, smem, s);
+    case 0: return (a->res ? launch_c1<64, 0, false>(k, smem, s) : launch_c1<64, 0, true>(k, smem, s));
+    case 1: return (a->res ? launch_c1<64, 1, false>(k, smem, s) : launch_c1<64, 1, true>(k, smem, s));
+    default: return (a->res ? launch_c1<64, 2, false>(k, smem, s) : launch_c1<64, 2, true>(k, smem, s));
   }
 }
