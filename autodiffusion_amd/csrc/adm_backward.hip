@@ -294,35 +294,47 @@ pool_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__
   for (int j = threadIdx.x; j < d; j += 64) { q0[j] = adm_bf16_to_f32(base[hd * d + j]); da[j] = da0[(long long)img * c + hd * d + j]; }
   __syncthreads();
   const float scale = rsqrtf((float)d);
+  const int d8 = d / 8;  // 16-byte segments per head row (d % 8 == 0)
   float delta = 0.f;
   for (int s = threadIdx.x; s < T; s += 64) {
     const uint16_t* vr = base + (long long)s * c3 + 2 * c + hd * d;
     float dw = 0.f;
-    for (int j = 0; j < d; ++j) dw += da[j] * adm_bf16_to_f32(vr[j]);
+    for (int j8 = 0; j8 < d8; ++j8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(vr + j8 * 8);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        dw += da[j8 * 8 + 2 * e] * __uint_as_float(u[e] << 16) + da[j8 * 8 + 2 * e + 1] * __uint_as_float(u[e] & 0xffff0000u);
+    }
     dlg[s] = dw;
     delta += w[s] * dw;
   }
   for (int off = 32; off >= 1; off >>= 1) delta += __shfl_xor(delta, off);
   __syncthreads();
-  for (int s = threadIdx.x; s < T; s += 64) {
-    const float dl = w[s] * (dlg[s] - delta) * scale;  // d logit_s / sqrt(d)
-    dlg[s] = dl;
-    uint16_t* orow = obase + (long long)s * c3;
-    for (int j = 0; j < d; ++j) {
-      orow[c + hd * d + j] = adm_f32_to_bf16(dl * q0[j]);          // dK
-      orow[2 * c + hd * d + j] = adm_f32_to_bf16(w[s] * da[j]);    // dV
-      if (s > 0) orow[hd * d + j] = 0;                              // dQ only exists for token 0
-    }
-  }
+  for (int s = threadIdx.x; s < T; s += 64) dlg[s] = w[s] * (dlg[s] - delta) * scale;  // d logit_s / sqrt(d)
   __syncthreads();
+  // dK, dV (and the zero dQ of tokens > 0, and the zero rows of the padding): 16-byte segments, lanes along a row
+  for (int it = threadIdx.x; it < tpad * d8; it += 64) {
+    const int s = it / d8, j8 = it % d8;
+    uint16_t* orow = obase + (long long)s * c3 + hd * d + j8 * 8;
+    uint32_t kk[4] = {0, 0, 0, 0}, vv[4] = {0, 0, 0, 0};
+    if (s < T) {
+      const float dl = dlg[s], ws = w[s];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j8 * 8 + 2 * e;
+        kk[e] = (uint32_t)adm_f32_to_bf16(dl * q0[j]) | ((uint32_t)adm_f32_to_bf16(dl * q0[j + 1]) << 16);
+        vv[e] = (uint32_t)adm_f32_to_bf16(ws * da[j]) | ((uint32_t)adm_f32_to_bf16(ws * da[j + 1]) << 16);
+      }
+    }
+    *reinterpret_cast<uint4*>(orow + c) = make_uint4(kk[0], kk[1], kk[2], kk[3]);
+    *reinterpret_cast<uint4*>(orow + 2 * c) = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+    if (s > 0) *reinterpret_cast<uint4*>(orow) = make_uint4(0, 0, 0, 0);  // dQ only exists for token 0
+  }
   for (int j = threadIdx.x; j < d; j += 64) {
     float acc = 0.f;
     for (int s = 0; s < T; ++s) acc += dlg[s] * adm_bf16_to_f32(base[(long long)s * c3 + c + hd * d + j]);
     obase[hd * d + j] = adm_f32_to_bf16(acc);
-  }
-  for (int s = T + threadIdx.x; s < tpad; s += 64) {
-    uint16_t* orow = obase + (long long)s * c3;
-    for (int j = 0; j < d; ++j) { orow[hd * d + j] = 0; orow[c + hd * d + j] = 0; orow[2 * c + hd * d + j] = 0; }
   }
 }
 
@@ -440,7 +452,7 @@ extern "C" int adm_pool_attn_fwd(const adm_bf16* qkv, float* a0, float* wts, int
 extern "C" int adm_pool_attn_bwd(const adm_bf16* qkv, const float* wts, const float* da0, adm_bf16* dqkv, int n, int t,
                                  int tpad, int heads, int d, void* stream) {
   ADM_REQUIRE(qkv && wts && da0 && dqkv, ADM_E_ARG, "adm_pool_attn_bwd: null pointer");
-  ADM_REQUIRE(n > 0 && t > 0 && tpad >= t && heads > 0 && d > 0 && n < 65536, ADM_E_ARG, "adm_pool_attn_bwd: bad shape");
+  ADM_REQUIRE(n > 0 && t > 0 && tpad >= t && heads > 0 && d > 0 && d % 8 == 0 && n < 65536, ADM_E_ARG, "adm_pool_attn_bwd: bad shape");
   hipLaunchKernelGGL(pool_attn_bwd_kernel, dim3(heads, n), dim3(64), (size_t)(2 * d + tpad) * 4, (hipStream_t)stream, qkv,
                      wts, da0, dqkv, t, tpad, heads, d);
   return adm_check_launch("adm_pool_attn_bwd");
