@@ -1179,13 +1179,13 @@ extern "C" int adm_pack_conv_weight32(const float* w, adm_bf16* out, int cout, i
 
 extern "C" int adm_conv_stat_slabs(const adm_conv_args* a) {
   if (!a) return 0;
-  if (const int bm = adm_conv1x1_resident_bm(a)) return a->h * a->w / bm;
+  if (const int sl = adm_conv1x1_resident_slabs(a)) return sl;
   return stat_slabs_for(a, pick_variant(a));
 }
 
 extern "C" int adm_conv_pick_variant(const adm_conv_args* a) {
   if (!a) return 0;
-  if (adm_conv1x1_resident_bm(a)) return 10;
+  if (adm_conv1x1_resident_cfg(a, nullptr)) return 10;
   return pick_variant(a);
 }
 
@@ -1208,7 +1208,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE((long long)a->n * a->h * a->w < (1ll << 31) / 4, ADM_E_SHAPE, "adm_conv: too many pixels for 32-bit index");
 
   // 1x1 with the activation tile resident in LDS across all Cout blocks (adm_conv1x1.hip)
-  if (const int bm = adm_conv1x1_resident_bm(a)) return adm_conv1x1_resident_launch(a, bm, stream);
+  if (adm_conv1x1_resident_cfg(a, nullptr)) return adm_conv1x1_resident_launch(a, stream);
   ADM_REQUIRE(a->variant != 10, ADM_E_SHAPE, "adm_conv: variant 10 (resident-tile 1x1) does not take this shape");
 
   ConvK k{};

@@ -49,10 +49,12 @@ template <int BM>
 constexpr int c1_lds_bytes(int k) { return BM * (2 * k + 32) + c1_stg_bytes<BM>() + 2 * k * 4; }
 
 // WP: wave-private barrier-free epilogue (outputs without a residual operand) or the block-wide two-half epilogue
-template <int BM, int PRO, bool WP>
+// WM: 1 = waves 1 x 8 (block BM x 384 channels, a wave owns all BM pixels); 2 = waves 2 x 4 (block BM x 192, a wave
+//     owns half the pixels: outputs no wider than 192 channels)
+template <int BM, int PRO, bool WP, int WM>
 __global__ void __launch_bounds__(512, 2)
 conv1x1r_kernel(const Conv1K p) {
-  constexpr int NT = 512, TM = BM / 16, TN = 3, BNH = 192;   // BNH: channels per block-epilogue half (4 waves x 48)
+  constexpr int NT = 512, WN = 8 / WM, BN = WN * 48, TM = BM / 16 / WM, TN = 3, BNH = 192;   // BNH: channels per block-epilogue half (4 waves x 48)
   constexpr int EROW = BNH * 2 + 16, SEGS = BNH / 8, PR = NT / SEGS, NIT = (BM + PR - 1) / PR;
   constexpr int WROW = 112, WST = 4096;   // wave-private restage: 32 pixels x (96 + 16 pad) bytes, in 4 KB per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,6 +66,7 @@ conv1x1r_kernel(const Conv1K p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lc = lane & 15, lq = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.Cout * 4, 0x00020000);
   const unsigned wstep = (unsigned)p.ntiles16 * 1024u;
@@ -130,14 +133,14 @@ conv1x1r_kernel(const Conv1K p) {
     }
     __syncthreads();
 
-    const unsigned char* const alane = A + lc * RB + lq * 16;  // fragment row of this lane inside a 16-pixel tile
+    const unsigned char* const alane = A + (wm * TM * 16 + lc) * RB + lq * 16;  // fragment row of this lane in its first pixel tile
     for (int nb = 0; nb < p.nblocks_n; ++nb) {
       // ---- K loop over the resident tile: no barrier, no global activation traffic
       unsigned wofs[TN];
       f32x4 acc[TM][TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int t16 = nb * 24 + wave * TN + j;
+        const int t16 = nb * (BN / 16) + wn * TN + j;
         wofs[j] = t16 < p.ntiles16 ? (unsigned)((t16 * 64 + lane) * 16) : OOB;
         const int bch = t16 * 16 + lq * 4;
         const uint4 b = bufload16(rsb, bch + 3 < p.Cout ? (unsigned)bch * 4u : OOB, 0);
@@ -196,7 +199,7 @@ conv1x1r_kernel(const Conv1K p) {
       // and accumulating the output's GroupNorm sums on the way.  LDS instructions of one wave execute in order, so
       // the restage needs no barrier -- and with none anywhere in the Cout loop the 8 waves drift apart: one wave's
       // stores overlap another's MFMAs (the layer is output-write bound at Cin = 384).
-      const int cbw = nb * 384 + wave * 48;             // first output channel of this wave
+      const int cbw = nb * BN + wn * 48;                // first output channel of this wave
       if (cbw < p.Cout) {                               // wave-uniform
         unsigned char* const wst = stg + wave * WST;
         const int sgl = lane % 6, rowl = lane / 6;      // lanes 0..59: segment sgl of pixel row rowl (+10 per step)
@@ -220,7 +223,7 @@ conv1x1r_kernel(const Conv1K p) {
           for (int q = 0; q < 4; ++q) {                 // rows rowl, +10, +20, +30 (< 32)
             const int r = rowl + q * 10;
             if (!lact || r >= 32) continue;
-            const long long eo = ((long long)pb + c * 32 + r) * p.Cout + cbw + sgl * 8;
+            const long long eo = ((long long)pb + wm * TM * 16 + c * 32 + r) * p.Cout + cbw + sgl * 8;
             uint4 v = *reinterpret_cast<const uint4*>(wst + r * WROW + sgl * 16);
             uint32_t a4[4] = {v.x, v.y, v.z, v.w};
             if (p.res) {
@@ -257,7 +260,7 @@ conv1x1r_kernel(const Conv1K p) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int q = 0; q < 10; ++q) { t1 += red[(q * 48 + lane) * 2]; t2 += red[(q * 48 + lane) * 2 + 1]; }
-            const int slab = (pb - img * p.HW) / BM;
+            const int slab = ((pb - img * p.HW) / BM) * WM + wm;   // one slab per (tile, pixel half)
             float* dst = p.stats + (((long long)img * p.stat_slabs + slab) * p.Cout + cbw + lane) * 2;
             dst[0] = t1;
             dst[1] = t2;
@@ -268,20 +271,20 @@ conv1x1r_kernel(const Conv1K p) {
       // ---- epilogue, two halves of 192 channels (waves 0-3, then 4-7)
       const int sgo = tid % SEGS, prow = tid / SEGS;
 #pragma unroll 1
-      for (int hf = 0; hf < 2; ++hf) {
-        const int cb = nb * 384 + hf * BNH;             // first output channel of this half
+      for (int hf = 0; hf < BN / BNH; ++hf) {
+        const int cb = nb * BN + hf * BNH;              // first output channel of this half
         if (cb >= p.Cout) break;                        // block-uniform
         __syncthreads();                                // staging buffer free
-        if ((wave >> 2) == hf) {
+        if (WM == 2 || (wave >> 2) == hf) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const int ch0 = ((wave & 3) * TN + j) * 16 + lq * 4;
+            const int ch0 = ((wn & 3) * TN + j) * 16 + lq * 4;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
               uint2 o;
               o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1]) << 16);
               o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3]) << 16);
-              *reinterpret_cast<uint2*>(stg + (i * 16 + lc) * EROW + ch0 * 2) = o;
+              *reinterpret_cast<uint2*>(stg + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
             }
           }
         }
@@ -337,10 +340,11 @@ conv1x1r_kernel(const Conv1K p) {
           if (tid < BNH && cb + tid < p.Cout) {
             float t1 = 0.f, t2 = 0.f;
             for (int q = 0; q < PR; ++q) { t1 += red[(q * BNH + tid) * 2]; t2 += red[(q * BNH + tid) * 2 + 1]; }
-            const int slab = (pb - img * p.HW) / BM;
+            const int slab = ((pb - img * p.HW) / BM) * WM;   // WM slabs per tile: the block-wide sum goes to the first
             float* dst = p.stats + (((long long)img * p.stat_slabs + slab) * p.Cout + cb + tid) * 2;
             dst[0] = t1;
             dst[1] = t2;
+            if (WM == 2) { dst[2 * p.Cout] = 0.f; dst[2 * p.Cout + 1] = 0.f; }
           }
         }
       }
@@ -349,13 +353,13 @@ conv1x1r_kernel(const Conv1K p) {
   }
 }
 
-template <int BM, int PRO, bool WP>
+template <int BM, int PRO, bool WP, int WM>
 int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
   static int slots_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   int& slots = slots_dev[dev & 63];
-  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO, WP>);
+  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO, WP, WM>);
   if (slots == 0) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv (1x1 resident): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -365,51 +369,64 @@ int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
     slots = ncu;  // one block per CU: the resident tile takes most of the LDS
   }
   const unsigned blocks = (unsigned)(k.m_tiles < slots ? k.m_tiles : slots);
-  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO, WP>), dim3(blocks), dim3(512), smem, s, k);
+  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO, WP, WM>), dim3(blocks), dim3(512), smem, s, k);
   return adm_check_launch("adm_conv");
 }
 
 }  // namespace
 
-// pixels per resident tile (128 or 64) if these arguments can run on the resident-tile kernel, else 0
-int adm_conv1x1_resident_bm(const adm_conv_args* a) {
+// tile configuration if these arguments can run on the resident-tile kernel: pixels per tile (128 or 64) and wave
+// rows (1: 384-wide Cout blocks; 2: 192-wide, for narrow outputs); returns 0 otherwise
+int adm_conv1x1_resident_cfg(const adm_conv_args* a, int* wm_out) {
   static const bool disabled = getenv("ADM_CONV_NO_RESIDENT") != nullptr;  // A/B switch for measurements
   if (disabled && a->variant == 0) return 0;
   if (a->taps != 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 10)) return 0;
   const int k = a->c0 + a->c1, hw = a->h * a->w;
   if (k % 64 != 0 || a->c0 % 8 != 0 || a->c1 % 8 != 0 || a->cout % 8 != 0 || hw % 64 != 0) return 0;
-  if (a->variant == 0 && a->cout < 256) return 0;   // narrow outputs: the 384-wide Cout block would idle half the waves
+  // narrow outputs: the 2 x 4 wave layout measured no faster than the staged kernel (its K loop is weight-load bound
+  // at 12 MFMAs per 3 fragment loads), so the automatic choice leaves them there; variant 10 still takes them
+  if (a->variant == 0 && a->cout < 256) return 0;
+  if (wm_out) *wm_out = a->cout <= 192 ? 2 : 1;
   const int lim = 160 * 1024;
   if (hw % 128 == 0 && c1_lds_bytes<128>(k) <= lim) return 128;
   if (c1_lds_bytes<64>(k) <= lim) return 64;
   return 0;
 }
 
-int adm_conv1x1_resident_launch(const adm_conv_args* a, int bm, void* stream) {
+int adm_conv1x1_resident_slabs(const adm_conv_args* a) {
+  int wm = 1;
+  const int bm = adm_conv1x1_resident_cfg(a, &wm);
+  return bm ? a->h * a->w / bm * wm : 0;
+}
+
+template <int BM, int WM>
+static int launch_c1_cfg(const adm_conv_args* a, const Conv1K& k, int smem, hipStream_t s) {
+  const bool wp = a->res == nullptr;
+  switch (a->prologue) {
+    case 0: return wp ? launch_c1<BM, 0, true, WM>(k, smem, s) : launch_c1<BM, 0, false, WM>(k, smem, s);
+    case 1: return wp ? launch_c1<BM, 1, true, WM>(k, smem, s) : launch_c1<BM, 1, false, WM>(k, smem, s);
+    default: return wp ? launch_c1<BM, 2, true, WM>(k, smem, s) : launch_c1<BM, 2, false, WM>(k, smem, s);
+  }
+}
+
+int adm_conv1x1_resident_launch(const adm_conv_args* a, void* stream) {
+  int wm = 1;
+  const int bm = adm_conv1x1_resident_cfg(a, &wm);
   Conv1K k{};
   k.in0 = a->in0; k.in1 = a->in1; k.w = a->w_packed; k.res = a->res;
   k.bias = a->bias; k.aa = a->aff_a; k.ab = a->aff_b; k.out = (uint16_t*)a->out; k.stats = a->out_stats;
   k.N = a->n; k.HW = a->h * a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
   k.ntiles16 = (a->cout + 15) / 16;
-  k.stat_slabs = k.HW / bm;
+  k.stat_slabs = k.HW / bm * wm;
   k.m_tiles = (int)((long long)a->n * k.HW / bm);
-  k.nblocks_n = (a->cout + 383) / 384;
+  const int bn = wm == 1 ? 384 : 192;
+  k.nblocks_n = (a->cout + bn - 1) / bn;
   const int kk = a->c0 + a->c1;
   k.wbytes = (unsigned)(((long long)kk / 32) * k.ntiles16 * 1024);
   const unsigned segk = (unsigned)kk / 8;
   k.rcp_seg = (unsigned)(((1ull << 32) + segk - 1) / segk);
   hipStream_t s = (hipStream_t)stream;
   const int smem = bm == 128 ? c1_lds_bytes<128>(kk) : c1_lds_bytes<64>(kk);
-  if (bm == 128) {
-    switch (a->prologue) {
-      case 0: return (a->res ? launch_c1<128, 0, false>(k, smem, s) : launch_c1<128, 0, true>(k, smem, s));
-      case 1: return (a->res ? launch_c1<128, 1, false>(k, smem, s) : launch_c1<128, 1, true>(k, smem, s));
-      default: return (a->res ? launch_c1<128, 2, false>(k, smem, s) : launch_c1<128, 2, true>(k, smem, s));
-    }
-  }
-  switch (a->prologue) {
-    case 0: return (a->res ? launch_c1<64, 0, false>(k, smem, s) : launch_c1<64, 0, true>(k, smem, s));
-    case 1: return (a->res ? launch_c1<64, 1, false>(k, smem, s) : launch_c1<64, 1, true>(k, smem, s));
-    default: return (a->res ? launch_c1<64, 2, false>(k, smem, s) : launch_c1<64, 2, true>(k, smem, s));
-  }
+  if (bm == 128) return wm == 1 ? launch_c1_cfg<128, 1>(a, k, smem, s) : launch_c1_cfg<128, 2>(a, k, smem, s);
+  return wm == 1 ? launch_c1_cfg<64, 1>(a, k, smem, s) : launch_c1_cfg<64, 2>(a, k, smem, s);
 }

@@ -181,7 +181,8 @@ CONV_CASES = [
     (2, 16, 64, 0, 384, 1, 1, False, False, 0),   # resident-tile 1x1 kernel (auto: Cout >= 256), 128-pixel tiles
     (3, 8, 128, 0, 256, 1, 0, True, False, 0),    # ... 64-pixel tiles (8x8 maps), ragged second half of the Cout block
     (2, 32, 64, 64, 448, 1, 2, True, False, 10),  # ... virtual concat, SiLU prologue, two Cout blocks (384 + 64)
-    (1, 16, 192, 0, 192, 1, 1, True, False, 10),  # ... forced on a narrow output
+    (1, 16, 192, 0, 192, 1, 1, True, False, 10),  # ... narrow output: 2 x 4 wave layout, block epilogue (residual)
+    (3, 16, 128, 64, 128, 1, 0, False, False, 10),  # ... narrow output, wave-private epilogue, concat, idle 4th column
     (2, 16, 64, 0, 192, 9, 2, True, False, 7),    # 32x32x16 MFMA kernel
     (1, 32, 64, 32, 384, 9, 0, False, False, 7),  # ... raw prologue, virtual concat, two channel blocks
     (3, 64, 32, 0, 96, 9, 1, True, False, 7),     # ... Cout below one tile: padded columns
@@ -252,7 +253,7 @@ def test_attention_softmax_is_stable_for_large_logits(ops):
 
 @pytest.mark.parametrize("n,hw,cin,cout,taps,variant", [(3, 16, 64, 192, 9, 0), (2, 32, 32, 96, 9, 0), (5, 8, 64, 192, 9, 0),
                                                          (2, 64, 32, 64, 1, 0), (2, 16, 32, 128, 9, 6), (3, 8, 64, 128, 1, 0),
-                                                         (2, 16, 64, 384, 1, 0), (3, 8, 128, 256, 1, 0)])  # resident-tile 1x1
+                                                         (2, 16, 64, 384, 1, 0), (3, 8, 128, 256, 1, 0), (2, 16, 64, 192, 1, 10)])  # resident-tile 1x1
 def test_conv_fused_output_statistics_feed_groupnorm(ops, n, hw, cin, cout, taps, variant):
     """The sums accumulated in the conv epilogue must give the same GroupNorm affine as a separate pass."""
     k = 3 if taps == 9 else 1
