@@ -44,8 +44,10 @@ attn_kernel(const AttnK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
-  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
-  const int qbase = blockIdx.x * QB + wave * QW;
+  int bx, by;
+  adm_xcd_block(bx, by);
+  const int n = by / p.heads, hd = by % p.heads;
+  const int qbase = bx * QB + wave * QW;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
             vcol = p.v_off + hd * p.head_stride;
@@ -223,8 +225,10 @@ attn_wide_kernel(const AttnK p) {
   __shared__ __attribute__((aligned(16))) uint16_t Vs[KT2 * KROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
-  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
-  const int q = blockIdx.x * QB2 + wave * 16 + lc;
+  int bx, by;
+  adm_xcd_block(bx, by);
+  const int n = by / p.heads, hd = by % p.heads;
+  const int q = bx * QB2 + wave * 16 + lc;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
             vcol = p.v_off + hd * p.head_stride;

@@ -38,8 +38,10 @@ attn_dq_kernel(const AttnBwdK p) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][TT * KROW];
   __shared__ __attribute__((aligned(16))) uint16_t Vs[2][TT * KROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
-  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
-  const int qbase = blockIdx.x * BB + wave * BW;
+  int bx, by;
+  adm_xcd_block(bx, by);
+  const int n = by / p.heads, hd = by % p.heads;
+  const int qbase = bx * BB + wave * BW;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
   const uint16_t* dbase = p.dout + (long long)n * p.T * p.C;
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;
@@ -180,8 +182,10 @@ attn_dkv_kernel(const AttnBwdK p) {
   __shared__ __attribute__((aligned(16))) uint16_t Gs[2][TT * KROW];
   __shared__ __attribute__((aligned(16))) float lse_s[2][TT], dl_s[2][TT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lq = lane >> 4;
-  const int n = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
-  const int kbase = blockIdx.x * BB + wave * BW;
+  int bx, by;
+  adm_xcd_block(bx, by);
+  const int n = by / p.heads, hd = by % p.heads;
+  const int kbase = bx * BB + wave * BW;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
   const uint16_t* dbase = p.dout + (long long)n * p.T * p.C;
   const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride, vcol = p.v_off + hd * p.head_stride;

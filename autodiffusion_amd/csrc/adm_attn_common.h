@@ -6,6 +6,19 @@ typedef __attribute__((ext_vector_type(4))) short adm_s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int adm_u32x4;
 typedef __attribute__((ext_vector_type(2))) float adm_f32x2;
 
+// XCD-aware block order for grids of (row blocks, image x head): the dispatcher deals consecutive linear block ids
+// round-robin to the 8 XCDs (each with its own L2), so with 8 row blocks per (image, head) every one of them would land
+// on a different XCD and each L2 would fetch that head's K / V separately.  Block L instead takes logical block
+// (L % 8) * ceil-share + L / 8: one XCD owns a contiguous run, i.e. all row blocks of a head share an L2.
+__device__ __forceinline__ void adm_xcd_block(int& bx, int& by) {
+  const unsigned nx = gridDim.x, total = gridDim.x * gridDim.y;
+  const unsigned lin = blockIdx.x + nx * blockIdx.y;
+  const unsigned share = total >> 3, rem = total & 7, xcd = lin & 7;
+  const unsigned logical = xcd * share + min(xcd, rem) + (lin >> 3);
+  bx = (int)(logical % nx);
+  by = (int)(logical / nx);
+}
+
 // MFMA A-operand fragment (16 rows x 32 k, bf16) of the TRANSPOSE of a row-major LDS tile, read with the
 // hardware transposing load ds_read_b64_tr_b16: lane (lc = l & 15, lq = l >> 4) receives
 //   element e (0..7) = tile[row0 + 16*(e>>2) + 4*lq + (e&3)][col0 + lc]
