@@ -64,6 +64,7 @@ struct ConvK {
   int tw_shift, thw_shift;   // log2(TW), log2(TH*TW)
   unsigned rcp_hpi, rcp_hw2; // ceil(2^20 / halo pixels per image), ceil(2^20 / halo row width): x / d == (x * rcp) >> 20 for x < 512
   int out_mode;
+  int in_up, res_up;         // the input (in0, no in1) / the residual is read through a virtual nearest-neighbour 2x upsample
   int ntiles16, nblocks_n;
   int total_tiles;           // pixel tiles x Cout blocks (persistent launch: blocks walk this list)
   unsigned wbytes;
@@ -237,7 +238,9 @@ conv_kernel(const ConvK p) {
   auto tile_setup = [&]() {
     const int nimg = min(p.TI, p.N - img0);  // images of this tile that exist
     // buffer descriptors over exactly the images this tile may touch: anything else reads as zero
-    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (long long)img0 * HWimg * p.C0), 0, nimg * HWimg * p.C0 * 2, 0x00020000);
+    // (with in_up the source map is (H/2) x (W/2): output-grid halo pixel (y, x) reads source pixel (y/2, x/2))
+    const int Hs = p.H >> p.in_up, Ws = p.W >> p.in_up;
+    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (long long)img0 * Hs * Ws * p.C0), 0, nimg * Hs * Ws * p.C0 * 2, 0x00020000);
     rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C1 ? p.in1 + (long long)img0 * HWimg * p.C1 : p.in0), 0,
                                             p.C1 ? nimg * HWimg * p.C1 * 2 : 0, 0x00020000);
     // the halo pixel of each pass is recomputed per tile from an opaque copy of the thread index: nothing
@@ -253,7 +256,7 @@ conv_kernel(const ConvK p) {
       const int ry = (int)(((unsigned)rem * p.rcp_hw2) >> 20), rx = rem - ry * HW2;
       const int y = y0 + ry - PAD, x = x0 + rx - PAD;
       const int ok = (int)(hp < HP) & (int)(ti < nimg) & (int)(y >= 0) & (int)(y < p.H) & (int)(x >= 0) & (int)(x < p.W);
-      pixrel[ps] = ok ? (ti * p.H + y) * p.W + x : -1;
+      pixrel[ps] = ok ? (ti * Hs + (y >> p.in_up)) * Ws + (x >> p.in_up) : -1;
     }
     // LDS-DMA of the tile's first chunk (see first_park): raw halo chunk 0, lane-linear into halo[0] ...
     const int seg_s = tid_s & (SEGP - 1), lane_s = tid_s & 63;
@@ -585,7 +588,9 @@ conv_kernel(const ConvK p) {
       // tile switch: they only need the first image of the finished tile)
       const long long ebase = (((long long)img0 * p.H + y0) * p.W + x0) * p.Cout + gch;  // element offset of the tile origin
       uint16_t* const obase = reinterpret_cast<uint16_t*>(p.out) + ebase;
-      const uint16_t* const rbase = p.res ? p.res + ebase : nullptr;
+      // residual through a virtual 2x upsample: source map (H/2) x (W/2); tile origins are even
+      const int Hr = p.H >> p.res_up, Wr = p.W >> p.res_up;
+      const uint16_t* const rbase = p.res ? p.res + (((long long)img0 * Hr + (y0 >> p.res_up)) * Wr + (x0 >> p.res_up)) * p.Cout + gch : nullptr;
       const int img0_d = img0;
       float* sdst[SGROUPS];
 #pragma unroll
@@ -636,7 +641,12 @@ conv_kernel(const ConvK p) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
           rr[g][k] = make_uint4(0, 0, 0, 0);
-          if (rbase && eoff[g][k] >= 0) rr[g][k] = *reinterpret_cast<const uint4*>(rbase + eoff[g][k]);
+          if (rbase && eoff[g][k] >= 0) {
+            const int m = g * RG + prow + k * PR;
+            const int ti = m >> p.thw_shift, rem = m & thw_mask;
+            const int roff = ((ti * Hr + ((rem >> p.tw_shift) >> p.res_up)) * Wr + ((rem & tw_mask) >> p.res_up)) * p.Cout;
+            rr[g][k] = *reinterpret_cast<const uint4*>(rbase + roff);
+          }
         }
       if (more) first_loads((tid_e & 63) >> 4);
       ADM_TSTAMP(ltile_done, 13);
@@ -1217,6 +1227,11 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   k.stats = a->out_stats; k.stat_slabs = 0;
   k.N = a->n; k.H = a->h; k.W = a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
   k.out_mode = a->out_mode;
+  k.in_up = a->in_up ? 1 : 0;
+  k.res_up = a->res_up ? 1 : 0;
+  ADM_REQUIRE(!(k.in_up || k.res_up) || (a->taps == 9 && a->out_mode == 0 && a->c1 == 0 && a->h % 2 == 0 && a->w % 2 == 0 && a->h >= 16 && a->w >= 16),
+              ADM_E_SHAPE, "adm_conv: in_up / res_up need a 3x3 conv with bf16 output, one input source and an even map >= 16x16");
+  ADM_REQUIRE(!k.res_up || a->res, ADM_E_ARG, "adm_conv: res_up without a residual operand");
   k.ntiles16 = (a->cout + 15) / 16;
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
@@ -1226,6 +1241,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     k.stat_slabs = stat_slabs_for(a, variant);
     ADM_REQUIRE(k.stat_slabs > 0, ADM_E_SHAPE, "adm_conv: fused output statistics are not offered for this shape / variant");
   }
+  ADM_REQUIRE(!(k.in_up || k.res_up) || variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: in_up / res_up need tiling variant 5 or 6");
   if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
     ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out");
     ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1, ADM_E_SHAPE, "adm_conv: variant 7 needs maps >= 16x16");

@@ -203,12 +203,16 @@ def pack_conv_weight32(w):
 
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
-         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False):
+         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): bf16 NHWC.  Returns bf16 NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].
+    in_up / res_up: x0 / res are at half resolution and are read through a virtual nearest-neighbour 2x upsample
+    (the output is [n, 2h, 2w, cout]): ResBlock(up=True) without materialising the upsampled tensors.
     """
     n, h, w, c0 = x0.shape
+    if in_up:
+        h, w = 2 * h, 2 * w
     c1 = 0 if x1 is None else x1.shape[3]
     dev = x0.device
     if out is None:
@@ -227,6 +231,9 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, c1, cout
     a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
+    a.in_up, a.res_up = int(in_up), int(res_up)
+    if in_up or res_up:
+        w_packed32 = None  # the 32x32x16 kernel does not take the virtual upsample
     if variant == 0:
         variant = _lib.load().adm_conv_pick_variant(C.byref(a))  # the library's own rule (incl. the resident-tile 1x1 kernel)
         if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw:

@@ -23,6 +23,8 @@ from __future__ import annotations
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 
 from . import ops
@@ -256,7 +258,15 @@ class AdmNet(HipModule):
             aff1 = (a1, b1)
         else:
             aff1 = ops.gn_affine(x0, d["g1"], d["b1"], x1)
-        if mode:
+        virtual_up = (mode == "up" and not s.has_skip_conv and tape is None and x0.shape[1] >= 8
+                      and not os.environ.get("ADM_NO_VIRTUAL_UP"))  # A/B switch for measurements
+        if virtual_up:
+            # h_upd(in_layers[:-1](x)) and x_upd(x) are never materialised: both convs read the half-resolution
+            # tensor through a nearest-neighbour 2x upsample (adm_conv_args.in_up / res_up)
+            assert x1 is None
+            h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, aff=aff1, silu=True, in_up=True, want_stats=True)
+            xs, xs1 = x0, None
+        elif mode:
             assert x1 is None
             h_in = ops.resample(x0, mode, aff1)
             xs = ops.resample(x0, mode)
@@ -277,7 +287,7 @@ class AdmNet(HipModule):
             res = ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=xs1)
         else:
             res = xs
-        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True)
+        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, res_up=virtual_up, want_stats=True)
 
     def _attention(self, pr, s: AttnSpec, x, skipped, tape=None):
         if skipped:  # dynamic_unet.py:316-318

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 1
+#define ADM_ABI_VERSION 2   /* 2: adm_conv_args gained in_up / res_up */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -156,6 +156,10 @@ typedef struct adm_conv_args {
   const adm_bf16* w_packed32; /* optional: the same weight in the 32x32x16 fragment order
                                  (adm_pack_conv_weight32); enables variant 7, the v_mfma_f32_32x32x16_bf16
                                  kernel for 3x3 convs on maps >= 16x16 */
+  int32_t in_up;     /* 1: in0 is [n][h/2][w/2][c0] and is read through a virtual nearest-neighbour 2x upsample (the
+                        prologue is applied on the way): ResBlock(up=True)'s h_upd(in_layers[:-1](x)) without the
+                        upsampled tensor ever existing.  3x3, bf16 output, c1 == 0, variant 0/5/6 only */
+  int32_t res_up;    /* 1: res is [n][h/2][w/2][cout], added through the same virtual upsample (x_upd(x)) */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

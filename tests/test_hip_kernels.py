@@ -217,6 +217,33 @@ def test_conv_fused(ops, case):
     assert_close_bf16(got, ref, f"conv {case}")
 
 
+@pytest.mark.parametrize("n,hs,cin,cout,prologue,in_up,res_up", [(2, 8, 64, 192, 2, True, False), (3, 16, 32, 128, 2, False, True),
+                                                              (1, 32, 64, 192, 1, True, True), (2, 8, 96, 64, 0, True, True)])
+def test_conv_virtual_upsample(ops, n, hs, cin, cout, prologue, in_up, res_up):
+    """ResBlock(up=True) (unet.py:236-249): conv(Upsample(act(GN(x)))) + Upsample(x) with the half-resolution tensors
+    read through a virtual nearest-neighbour 2x upsample inside the conv."""
+    h2 = 2 * hs
+    x = bf(rnd((n, cin, hs if in_up else h2, hs if in_up else h2), 1))
+    w = rnd((cout, cin, 3, 3), 2, (cin * 9) ** -0.5)
+    b = rnd((cout,), 3, 0.1)
+    a_, b_ = 1 + 0.2 * rnd((n, cin), 4), 0.2 * rnd((n, cin), 5)
+    res = bf(rnd((n, cout, hs if res_up else h2, hs if res_up else h2), 6))
+    h = x
+    if prologue:
+        h = a_[:, :, None, None] * x + b_[:, :, None, None]
+        if prologue == 2:
+            h = F.silu(h)
+    h = bf(h)
+    if in_up:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, bf(w), b, padding=1) + (F.interpolate(res, scale_factor=2, mode="nearest") if res_up else res)
+    got = ops.conv(nhwc_dev(x), ops.pack_conv_weight(w.to(DEV)), b.to(DEV), cout, 9,
+                   aff=(a_.to(DEV), b_.to(DEV)) if prologue else None, silu=(prologue == 2),
+                   res=nhwc_dev(res), in_up=in_up, res_up=res_up, want_stats=True)
+    assert got.shape == (n, h2, h2, cout)
+    assert_close_bf16(nchw_cpu(got), ref, f"virtual upsample {n, hs, cin, cout, prologue, in_up, res_up}")
+
+
 def test_conv_rejects_bad_shapes(ops):
     from autodiffusion_amd._lib import AdmError
     x = torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=DEV)
