@@ -679,7 +679,10 @@ conv_kernel(const ConvK p) {
             }
             v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
           }
-          *reinterpret_cast<uint4*>(obase + eoff[g][k]) = v;
+          {
+            typedef __attribute__((ext_vector_type(4))) unsigned int nt_u32x4;
+            __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(obase + eoff[g][k]));
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)};
