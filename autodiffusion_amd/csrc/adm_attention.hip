@@ -20,7 +20,8 @@ namespace {
 constexpr int KT = 64;        // keys per tile
 constexpr int QW = 32;        // queries per wave
 constexpr int QB = 128;       // queries per block
-constexpr int PADE = 8;       // bf16 elements of row padding
+constexpr int PADE = 16;      // bf16 elements of row padding: row stride = D/2 + 8 dwords = 8 (mod 16), which keeps both the
+                              // ds_read_b128 fragment reads and the ds_read_b64_tr_b16 transposing reads bank-conflict free
 
 struct AttnK {
   const uint16_t* qkv; uint16_t* out; float* lse;

@@ -19,7 +19,7 @@ namespace {
 constexpr int TT = 64;        // streamed tile (keys for dQ, queries for dK/dV)
 constexpr int BW = 32;        // rows (queries / keys) owned per wave
 constexpr int BB = 128;       // rows per block
-constexpr int PADE = 8;
+constexpr int PADE = 16;      // see adm_attention.hip: conflict-free row stride
 
 struct AttnBwdK {
   const uint16_t* qkv; const uint16_t* out; const uint16_t* dout; const float* lse; const float* delta;
