@@ -338,3 +338,186 @@ class EvolutionSearcher(object):
             self.get_random(self.population_num)
             self.epoch += 1
         self.flush_pending()
+
+
+class DynamicEvolutionSearcher(EvolutionSearcher):
+    """Joint search over timesteps AND per-step layer-skip lists on the dynamic UNet: the reference's
+    search_dynamic_unet_imagenet64_classifier_guidance_progressive.py (EvolutionSearcher, :155-715).
+
+    A candidate is ``{'timesteps': [t_0, ...], 'skip_layers': [[layer ids skipped at t_0], ...]}``; its budget is
+    ``max_index_number`` = time_step * layer_num evaluated layers (or ``index_step``).  The fraction of layers a step may
+    skip is drawn from ``skip_layer_range``, which the search opens progressively: [0, 0] until the best candidate
+    stalls (or epoch 5), then the upper end grows by max_prun / 5 per epoch up to max_prun, and from epoch 6 the lower end
+    is min_prun (:684-692).  Every operator consumes ``random`` / ``np.random`` in the reference's order, including its
+    quirks -- the list comparison that decides whether a crossover child is padded from a parent (:494-500) and the
+    skip-list mutation that draws its replacement but leaves the list unchanged (``==`` at :568, :632) -- because the
+    candidate sequence is the data contract (pinned by tests/golden/ea_dynamic_trajectory.npz).
+    """
+
+    def __init__(self, args, model, base_diffusion, time_step, classifier=None, index_step=None, **kw):
+        kw.setdefault("variant", "guided")
+        super().__init__(args, model, base_diffusion, time_step, classifier=classifier, **kw)
+        self.init_time_step = time_step
+        self.model_layers = model.layer_num if model is not None else int(getattr(args, "layer_num"))
+        self.max_index_number = time_step * self.model_layers
+        if index_step is not None:
+            self.max_index_number = eval(index_step) if isinstance(index_step, str) else int(index_step)
+        self.max_prun = args.max_prun
+        self.min_prun = args.min_prun
+        self.skip_layer_range = [0, 0]
+        self.last_best_cand = None
+
+    def cand2gen(self, cand):
+        """Flat index encoding (layer + layer_num * timestep of every evaluated layer), zero-padded (:207-217)."""
+        ret = []
+        for t, skipped in zip(cand['timesteps'], cand['skip_layers']):
+            kept = [k for k in range(self.model_layers) if k not in skipped]
+            ret += [k + self.model_layers * t for k in kept]
+        return ret + [0] * max(0, self.max_index_number - len(ret))
+
+    # ------------------------------------------------------------------ operators (reference order of RNG draws)
+    def _draw_skips(self, count):
+        layers = [i for i in range(self.model_layers)]
+        random.shuffle(layers)
+        return layers[:count]
+
+    def sample_active_subnet(self):
+        lo, hi = self.skip_layer_range
+        L, budget = self.model_layers, self.max_index_number
+        use_timestep = [i for i in range(self.base_diffusion.original_num_steps)]
+        random.shuffle(use_timestep)
+        used, timesteps, skips = 0, [], []
+        while True:
+            n_skip = None
+            tries = 0
+            while n_skip is None or used + L - n_skip > budget:   # redraw until this step fits the budget
+                n_skip = int((np.random.random_sample() * (hi - lo) + lo) * L)
+                tries += 1
+                if tries > 10 ** 6:
+                    raise RuntimeError("sample_active_subnet: no skip count fits the index budget")
+            skips.append(self._draw_skips(n_skip))
+            timesteps.append(use_timestep[len(timesteps)])
+            used += L - n_skip
+            least = L - int(L * hi)                                # the cheapest step still allowed
+            if used + least > budget:
+                break
+            if used + least == budget:                             # exactly one maximally pruned step fits
+                skips.append(self._draw_skips(int(L * hi)))
+                timesteps.append(use_timestep[len(timesteps)])
+                break
+        return {'timesteps': timesteps, 'skip_layers': skips}
+
+    def _mutate_timesteps(self, cand, m_prob):
+        pool = [i for i in range(self.base_diffusion.original_num_steps) if i not in cand['timesteps']]
+        for i in range(len(cand['timesteps'])):
+            if np.random.random_sample() < m_prob:
+                new_c = random.choice(pool)
+                del pool[pool.index(new_c)]
+                cand['timesteps'][i] = new_c
+                if len(pool) == 0:
+                    break
+
+    def _touch_skips(self, skipped, m_prob):
+        """The reference draws a replacement layer per mutated entry but never stores it: RNG draws only."""
+        pool = [j for j in range(self.model_layers) if j not in skipped]
+        for _ in range(len(skipped)):
+            if np.random.random_sample() < m_prob:
+                new_c = random.choice(pool)
+                del pool[pool.index(new_c)]
+                if len(pool) == 0:
+                    break
+
+    def _mutate(self, cand, m_prob, fill_empty=True):
+        self._mutate_timesteps(cand, m_prob)
+        if self.skip_layer_range[1] == 0:
+            return cand
+        lo, hi = self.skip_layer_range
+        for i in range(len(cand['skip_layers'])):
+            if fill_empty and len(cand['skip_layers'][i]) == 0:
+                if np.random.random_sample() < m_prob:             # an unpruned step gets a fresh skip list
+                    n_skip = int((np.random.random_sample() * (hi - lo) + lo) * self.model_layers)
+                    cand['skip_layers'][i] = self._draw_skips(n_skip)
+            else:
+                self._touch_skips(cand['skip_layers'][i], m_prob)
+        return cand
+
+    def get_cross(self, k, cross_num):
+        assert k in self.keep_top_k
+        logger.log('cross ......')
+        res = []
+        max_iters = cross_num * 10
+        while len(res) < cross_num and max_iters > 0:
+            max_iters -= 1
+            cand1 = eval(choice(self.keep_top_k[k]))
+            cand2 = eval(choice(self.keep_top_k[k]))
+            child = {'timesteps': [], 'skip_layers': []}
+            for i in range(min(len(cand1['timesteps']), len(cand2['timesteps']))):
+                src = cand1 if np.random.random_sample() < 0.5 else cand2
+                child['timesteps'].append(src['timesteps'][i])
+                child['skip_layers'].append(src['skip_layers'][i])
+            for parent in (cand1, cand2):                          # list (lexicographic) comparison, as in the reference
+                if child['timesteps'] < parent['timesteps']:
+                    child['timesteps'] += parent['timesteps'][len(child['timesteps']):]
+                    child['skip_layers'] += parent['skip_layers'][len(child['skip_layers']):]
+            cand = str(child)
+            if not self.is_legal(cand):
+                continue
+            res.append(cand)
+            logger.log('cross {}/{}'.format(len(res), cross_num))
+        logger.log('cross_num = {}'.format(len(res)))
+        return res
+
+    def mutate_init_x(self, x0, mutation_num, m_prob):
+        logger.log('mutation x0 ......')
+        res = []
+        max_iters = mutation_num * 10
+        while len(res) < mutation_num and max_iters > 0:
+            max_iters -= 1
+            cand = str(self._mutate(eval(x0), m_prob, fill_empty=False))
+            if not self.is_legal_before_search(cand):
+                continue
+            res.append(cand)
+            logger.log('mutation x0 {}/{}'.format(len(res), mutation_num))
+        logger.log('mutation_num = {}'.format(len(res)))
+        return res
+
+    def search(self):
+        args = self.args
+        logger.log('population_num = {} select_num = {} mutation_num = {} crossover_num = {} random_num = {} max_epochs = {}'.format(
+            self.population_num, self.select_num, self.mutation_num, self.crossover_num,
+            self.population_num - self.mutation_num - self.crossover_num, self.max_epochs))
+        if getattr(args, "use_ddim_init_x", False) is False:
+            self.get_random_before_search(self.population_num)
+        else:
+            steps = self.base_diffusion.original_num_steps
+            init_x = list(space_timesteps(steps, ('ddim' if args.use_ddim else '') + str(args.time_step)))
+            init_cand = str({'timesteps': init_x, 'skip_layers': [[] for _ in init_x]})
+            self.is_legal_before_search(init_cand)
+            self.candidates.append(init_cand)
+            self.get_random_before_search(self.population_num // 2 + 1)
+            self.candidates += self.mutate_init_x(x0=init_cand, mutation_num=self.population_num - self.population_num // 2 - 1,
+                                                  m_prob=0.1)
+        while self.epoch < self.max_epochs:
+            logger.log('epoch = {}'.format(self.epoch))
+            self.flush_pending()
+            self.update_top_k(self.candidates, k=self.select_num, key=lambda x: self.vis_dict[x]['fid'])
+            self.update_top_k(self.candidates, k=50, key=lambda x: self.vis_dict[x]['fid'])
+            logger.log('epoch = {} : top {} result'.format(self.epoch, len(self.keep_top_k[50])))
+            for i, cand in enumerate(self.keep_top_k[50]):
+                logger.log('No.{} {} fid = {}'.format(i + 1, cand, self.vis_dict[cand]['fid']))
+            best = self.keep_top_k[50][0]
+            if self.skip_layer_range[1] == 0 and (self.last_best_cand == best or self.epoch > 4):
+                self.skip_layer_range[1] = self.max_prun / 5
+            elif 0 < self.skip_layer_range[1] < self.max_prun:
+                self.skip_layer_range[1] += self.max_prun / 5
+            if self.skip_layer_range[0] == 0 and self.epoch > 5:
+                self.skip_layer_range[0] = self.min_prun
+            self.last_best_cand = best
+            logger.log('skip_layer_range_left = {} , skip_layer_range_right {}'.format(*self.skip_layer_range))
+            if self.epoch + 1 == self.max_epochs:
+                break
+            self.candidates = self.get_mutation(self.select_num, self.mutation_num, self.m_prob)
+            self.candidates += self.get_cross(self.select_num, self.crossover_num)
+            self.get_random(self.population_num)
+            self.epoch += 1
+        self.flush_pending()

@@ -11,6 +11,10 @@ What this build needs from the user that the reference downloaded: the Inception
 ``features(uint8 NHWC device batch) -> fp32 [B, dim]``; ``--ref_path`` is an .npz with ``mu``, ``sigma``
 (written from the reference's pickled FIDStatistics).  ``--population_parallel True`` shards whole
 candidates over ranks; otherwise every candidate's images are sharded and the statistics pooled.
+
+``--use_dynamic_unet True`` runs the joint timestep + layer-skip search of
+search_dynamic_unet_imagenet64_classifier_guidance_progressive.py (flags ``--index_step``, ``--max_prun``,
+``--min_prun`` as there, :717-748): candidates are {'timesteps': [...], 'skip_layers': [[...], ...]}.
 """
 import argparse
 import importlib
@@ -29,7 +33,7 @@ from autodiffusion_amd.schedule import space_timesteps  # noqa: E402
 from autodiffusion_amd.script_util import (add_dict_to_argparser, args_to_dict, classifier_defaults,  # noqa: E402
                                            create_classifier, create_model_and_diffusion,
                                            model_and_diffusion_defaults)
-from autodiffusion_amd.search import EvolutionSearcher  # noqa: E402
+from autodiffusion_amd.search import DynamicEvolutionSearcher, EvolutionSearcher  # noqa: E402
 
 
 def create_argparser():
@@ -39,6 +43,7 @@ def create_argparser():
         m_prob=0.1, crossover_num=25, mutation_num=35, classifier_path="", classifier_scale=1.0, max_fid=48.0,
         thres=0.2, use_ddim_init_x=False, search_space="", ref_path="", MASTER_PORT="12344", init_x="",
         without_classifier=False, features="", population_parallel=False,
+        index_step=None, max_prun=0.0, min_prun=0.0,
     )
     defaults.update(model_and_diffusion_defaults())
     defaults.update(classifier_defaults())
@@ -95,9 +100,14 @@ def main(argv=None):
     if search_space is not None:
         logger.log("search space: " + str(search_space))
     t = time.time()
-    searcher = EvolutionSearcher(args, model=model, base_diffusion=diffusion, time_step=args.time_step,
-                                 classifier=classifier, search_space=search_space, features=features,
-                                 feature_dim=dim, population_parallel=args.population_parallel)
+    if args.use_dynamic_unet:
+        searcher = DynamicEvolutionSearcher(args, model=model, base_diffusion=diffusion, time_step=args.time_step,
+                                            classifier=classifier, index_step=args.index_step, features=features,
+                                            feature_dim=dim, population_parallel=args.population_parallel)
+    else:
+        searcher = EvolutionSearcher(args, model=model, base_diffusion=diffusion, time_step=args.time_step,
+                                     classifier=classifier, search_space=search_space, features=features,
+                                     feature_dim=dim, population_parallel=args.population_parallel)
     searcher.search()
     logger.log("total searching time = {:.2f} hours".format((time.time() - t) / 3600))
 

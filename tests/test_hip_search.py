@@ -60,6 +60,43 @@ def test_get_cand_fid_end_to_end(monkeypatch):
     assert np.isfinite(fid2) and fid2 != fid
 
 
+def test_dynamic_search_end_to_end(monkeypatch):
+    """The joint timestep + layer-skip search (search_dynamic_unet_..._progressive.py) on the HIP evaluation path: a tiny
+    population for a few epochs on the small dynamic model, FIDs from the GPU statistics path; every evaluated
+    candidate respects the layer budget and the result is reproducible."""
+    import random
+    from autodiffusion_amd import logger, search
+    from autodiffusion_amd.fid import FIDStatistics
+    model, clf, diffusion = _setup()
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    proj = torch.randn(3 * 64 * 64, 32, generator=torch.Generator().manual_seed(5)).to(DEV) / 100.0
+    features = lambda u8: u8.reshape(u8.shape[0], -1).float() @ proj  # noqa: E731
+    ref = FIDStatistics(np.zeros(32), np.eye(32))
+
+    def run():
+        args = SimpleNamespace(max_epochs=3, select_num=2, population_num=4, m_prob=0.5, crossover_num=1, mutation_num=2,
+                               batch_size=4, num_samples=8, image_size=64, use_ddim=True, clip_denoised=True,
+                               class_cond=True, classifier_scale=1.0, seed=0, time_step=3, use_ddim_init_x=True,
+                               max_fid=48.0, max_prun=0.5, min_prun=0.1)
+        s = search.DynamicEvolutionSearcher(args, model, diffusion, 3, classifier=clf, features=features, feature_dim=32,
+                                            ref_stats=ref)
+        s.skip_layer_range = [0.0, 0.3]  # open the skip range from the start so that pruned candidates are evaluated
+        random.seed(2)
+        np.random.seed(2)
+        s.search()
+        return s
+    s = run()
+    L = model.layer_num
+    assert s.max_index_number == 3 * L and len(s.vis_dict) >= 8
+    for c, info in s.vis_dict.items():
+        cand = eval(c)
+        assert np.isfinite(info["fid"]) and sum(L - len(sk) for sk in cand["skip_layers"]) <= s.max_index_number
+    assert any(any(len(sk) for sk in eval(c)["skip_layers"]) for c in s.vis_dict)
+    s2 = run()
+    assert s2.keep_top_k[50] == s.keep_top_k[50]
+    assert [s2.vis_dict[c]["fid"] for c in s2.keep_top_k[50]] == [s.vis_dict[c]["fid"] for c in s.keep_top_k[50]]
+
+
 def test_full_size_adm64_properties():
     """BASELINE-size architecture (ADM-G ImageNet-64, 296 M parameters): size-independent properties."""
     if not torch.cuda.is_available():

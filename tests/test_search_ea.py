@@ -113,3 +113,68 @@ def test_population_parallel_two_ranks_gloo(tmp_path):
     for z in (z0, z1):                                               # every rank ends with the same result
         assert z["top"].tolist() == g["top50"].tolist()
         np.testing.assert_array_equal(z["fid"], g["top50_fid"])
+
+
+# ------------------------------------------------------------------ dynamic (timesteps + layer-skip) search
+def _dyn_fitness(cand):
+    """Same synthetic fitness as tests/golden/capture_ea_dynamic.py::fitness_of."""
+    ts = np.sort(np.array(cand["timesteps"], dtype=np.float64))
+    tgt = np.array([150.0, 420.0, 690.0, 930.0])
+    k = min(len(ts), len(tgt))
+    f = float(np.abs(ts[:k] - tgt[:k]).sum() / 10.0) + 3.0 * abs(len(ts) - len(tgt))
+    skipped = sum(len(s) for s in cand["skip_layers"])
+    return f - 0.05 * skipped + 0.001 * sum(sum(s) for s in cand["skip_layers"])
+
+
+def _dyn_searcher(max_epochs, use_ddim_init_x, layers, **kw):
+    args = SimpleNamespace(max_epochs=max_epochs, select_num=4, population_num=10, m_prob=0.25, crossover_num=3,
+                           mutation_num=5, max_fid=48.0, max_prun=0.5, min_prun=0.1, use_ddim_init_x=use_ddim_init_x,
+                           use_ddim=True, time_step=4, init_x="", layer_num=layers)
+    base = create_gaussian_diffusion(steps=1000, learn_sigma=True, noise_schedule="cosine")
+    s = search.DynamicEvolutionSearcher(args, model=None, base_diffusion=base, time_step=4, **kw)
+    evaluated, ranges = [], []
+
+    def fitness(cand=None, args=None):
+        evaluated.append(str(cand))
+        ranges.append(list(s.skip_layer_range))
+        return _dyn_fitness(cand)
+    s.get_cand_fid = fitness
+    return s, evaluated, ranges
+
+
+def test_dynamic_ea_trajectory_matches_reference(monkeypatch):
+    """Golden: tests/golden/ea_dynamic_trajectory.npz, recorded from the reference's dynamic EvolutionSearcher
+    (search_dynamic_unet_imagenet64_classifier_guidance_progressive.py) under the synthetic fitness above: every
+    candidate string, in evaluation order, the progressive skip-layer range at each evaluation, the final population
+    and the top list must be identical."""
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    g = golden("ea_dynamic_trajectory")
+    layers = int(g["layers"])
+    for tag, (epochs, seed, init) in {"a": (9, 0, True), "b": (8, 3, False)}.items():
+        s, evaluated, ranges = _dyn_searcher(epochs, init, layers)
+        random.seed(seed)
+        np.random.seed(seed)
+        s.search()
+        assert evaluated == g[f"{tag}_evaluated"].tolist(), tag
+        np.testing.assert_array_equal(np.array(ranges, dtype=np.float64), g[f"{tag}_ranges"])
+        assert s.candidates == g[f"{tag}_final_candidates"].tolist()
+        assert s.keep_top_k[50] == g[f"{tag}_top50"].tolist()
+        np.testing.assert_array_equal([s.vis_dict[c]["fid"] for c in s.keep_top_k[50]], g[f"{tag}_top50_fid"])
+        np.testing.assert_array_equal(np.array(s.skip_layer_range, dtype=np.float64), g[f"{tag}_final_range"])
+    # the search did open the skip range and produce pruned candidates
+    assert any("skip_layers': [[]" not in c for c in evaluated)
+
+
+def test_dynamic_candidates_respect_the_index_budget(monkeypatch):
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    s, _, _ = _dyn_searcher(1, False, 14)
+    s.skip_layer_range = [0.1, 0.5]
+    random.seed(5)
+    np.random.seed(5)
+    for _ in range(50):
+        c = s.sample_active_subnet()
+        assert len(c["timesteps"]) == len(c["skip_layers"]) == len(set(c["timesteps"]))
+        used = sum(14 - len(sk) for sk in c["skip_layers"])
+        assert used <= s.max_index_number and all(len(set(sk)) == len(sk) and all(0 <= l < 14 for l in sk) for sk in c["skip_layers"])
+        gen = s.cand2gen(c)
+        assert len(gen) == s.max_index_number
