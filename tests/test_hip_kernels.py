@@ -181,6 +181,8 @@ CONV_CASES = [
     (2, 16, 64, 0, 384, 1, 1, False, False, 0),   # resident-tile 1x1 kernel (auto: Cout >= 256), 128-pixel tiles
     (3, 8, 128, 0, 256, 1, 0, True, False, 0),    # ... 64-pixel tiles (8x8 maps), ragged second half of the Cout block
     (2, 32, 64, 64, 448, 1, 2, True, False, 10),  # ... virtual concat, SiLU prologue, two Cout blocks (384 + 64)
+    (2, 8, 768, 0, 2304, 1, 1, False, False, 0),  # ... ADM-64's 8x8 qkv: 64-pixel tiles, 6 Cout blocks, wave-private epilogue
+    (1, 16, 576, 0, 1728, 1, 1, False, False, 0),  # ... 16x16 qkv: K = 576 (64-pixel tiles by LDS size), ragged last Cout block
     (1, 16, 192, 0, 192, 1, 1, True, False, 10),  # ... narrow output: 2 x 4 wave layout, block epilogue (residual)
     (3, 16, 128, 64, 128, 1, 0, False, False, 10),  # ... narrow output, wave-private epilogue, concat, idle 4th column
     (2, 16, 64, 0, 192, 9, 2, True, False, 7),    # 32x32x16 MFMA kernel
