@@ -44,7 +44,12 @@ __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 template <int BM>
-constexpr int c1_stg_bytes() { return BM * (192 * 2 + 16) > (512 / 24) * 192 * 8 ? BM * (192 * 2 + 16) : (512 / 24) * 192 * 8; }
+constexpr int c1_stg_bytes() {
+  // the larger of: block-epilogue staging (BM rows x 400 B), its statistics reduction ([21][192][2] floats), and the
+  // eight wave-private 4 KB regions of the barrier-free epilogue
+  constexpr int a = BM * (192 * 2 + 16), b = (512 / 24) * 192 * 8, c = 8 * 4096;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
 template <int BM>
 constexpr int c1_lds_bytes(int k) { return BM * (2 * k + 32) + c1_stg_bytes<BM>() + 2 * k * 4; }
 
