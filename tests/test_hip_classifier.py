@@ -60,6 +60,29 @@ def test_attention_backward_matches_autograd(ops, n, heads, d, t, new_order):
     assert rel(got, ref) < 1.5e-2, rel(got, ref)
 
 
+def test_attention_forward_backward_random_shapes(ops):
+    """Seeded sweep over sequence lengths that leave ragged query / key tiles, head counts and both qkv orders:
+    forward against the oracle, backward against PyTorch-CPU autograd of the oracle."""
+    import numpy as np
+    from oracle import nets
+    rng = np.random.RandomState(77)
+    for it in range(12):
+        n, heads = int(rng.randint(1, 4)), int(rng.randint(1, 5))
+        d = int(rng.choice([32, 64]))
+        t = int(rng.randint(16, 300))
+        new_order = bool(rng.rand() < 0.5)
+        qkv = bf(rnd((n, 3 * heads * d, t), 900 + it)).requires_grad_(True)
+        dout = bf(rnd((n, heads * d, t), 950 + it))
+        out = nets.qkv_attention(qkv, heads, new_order)
+        (ref,) = torch.autograd.grad(out, qkv, dout)
+        q_dev = qkv.detach().permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+        a, lse = ops.attention(q_dev, heads, new_order, want_lse=True)
+        case = (it, n, heads, d, t, new_order)
+        assert rel(a.float().cpu().permute(0, 2, 1), out.detach()) < 1e-2, case
+        dq = ops.attention_bwd(q_dev, a, dout.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV), lse, heads, new_order)
+        assert rel(dq.float().cpu().permute(0, 2, 1), ref) < 1.5e-2, case
+
+
 @pytest.mark.parametrize("silu,film,half", [(True, True, False), (False, False, False), (True, False, True)])
 def test_gn_silu_backward_matches_autograd(ops, silu, film, half):
     n, c, hw = 3, 64, 16

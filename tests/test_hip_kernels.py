@@ -246,6 +246,48 @@ def test_conv_virtual_upsample(ops, n, hs, cin, cout, prologue, in_up, res_up):
     assert_close_bf16(nchw_cpu(got), ref, f"virtual upsample {n, hs, cin, cout, prologue, in_up, res_up}")
 
 
+def test_conv_random_shapes(ops):
+    """Seeded sweep over shapes the fixed cases do not list: batch sizes that leave ragged tiles, virtual concat splits,
+    Cout that pads the 192/128-wide blocks, 3x3 and 1x1 (staged and resident-tile kernels), every prologue, residual and
+    fused statistics on or off -- each against the PyTorch-CPU fp32 reference of the same op."""
+    rng = np.random.RandomState(1234)
+    for it in range(24):
+        taps = int(rng.choice([1, 9]))
+        hw = int(rng.choice([8, 16, 32]))
+        n = int(rng.randint(1, 6))
+        c0 = 32 * int(rng.randint(1, 7))
+        c1 = 32 * int(rng.randint(0, 4)) if rng.rand() < 0.4 else 0
+        cout = 8 * int(rng.randint(1, 60))
+        prologue = int(rng.randint(0, 3))
+        use_res = bool(rng.rand() < 0.5)
+        want_stats = bool(rng.rand() < 0.5) and hw >= 8
+        cin = c0 + c1
+        k = 3 if taps == 9 else 1
+        x = bf(rnd((n, cin, hw, hw), 100 + it))
+        w = rnd((cout, cin, k, k), 200 + it, (cin * taps) ** -0.5)
+        b = rnd((cout,), 300 + it, 0.1)
+        a_, b_ = 1 + 0.2 * rnd((n, cin), 400 + it), 0.2 * rnd((n, cin), 500 + it)
+        res = bf(rnd((n, cout, hw, hw), 600 + it))
+        h = x
+        if prologue:
+            h = a_[:, :, None, None] * x + b_[:, :, None, None]
+            if prologue == 2:
+                h = F.silu(h)
+        ref = F.conv2d(bf(h), bf(w), b, padding=k // 2) + (res if use_res else 0)
+        got = ops.conv(nhwc_dev(x[:, :c0]), ops.pack_conv_weight(w.to(DEV)), b.to(DEV), cout, taps,
+                       x1=nhwc_dev(x[:, c0:]) if c1 else None,
+                       aff=(a_.to(DEV), b_.to(DEV)) if prologue else None, silu=(prologue == 2),
+                       res=nhwc_dev(res) if use_res else None, want_stats=want_stats)
+        case = (it, n, hw, c0, c1, cout, taps, prologue, use_res, want_stats)
+        assert_close_bf16(nchw_cpu(got), ref, f"conv random {case}")
+        st = getattr(got, "_adm_stats", None)
+        if st is not None:  # fused per-(image, channel) sums of the stored output
+            part = st[0].sum(dim=1).cpu()
+            yv = got.float().cpu()
+            torch.testing.assert_close(part[..., 0], yv.sum(dim=(1, 2)), rtol=2e-3, atol=2e-2)
+            torch.testing.assert_close(part[..., 1], (yv * yv).sum(dim=(1, 2)), rtol=2e-3, atol=2e-2)
+
+
 def test_conv_rejects_bad_shapes(ops):
     from autodiffusion_amd._lib import AdmError
     x = torch.zeros((1, 4, 4, 32), dtype=torch.bfloat16, device=DEV)
