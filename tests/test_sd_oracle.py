@@ -1,0 +1,39 @@
+"""Pin the Stable-Diffusion latent-UNet oracle against golden vectors captured from the reference's own modules
+(tests/golden/capture_sd.py -> sd_unet_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from autodiffusion_amd.sd_arch import SD_V1, sd_unet_plan
+from oracle import sd_nets
+from oracle.fill import fill_state_dict
+
+from helpers import golden
+
+
+def sd_case(name):
+    g = golden(name)
+    cfg = eval(str(g["cfg"]), {"__builtins__": {}})  # a dict literal written by capture_sd.py
+    plan = sd_unet_plan(**cfg)
+    P = {k: torch.from_numpy(v) for k, v in fill_state_dict(plan.param_shapes()).items()}
+    return g, plan, P
+
+
+@pytest.mark.parametrize("name", ["sd_unet_tiny", "sd_unet_w320"])
+def test_sd_unet_oracle_matches_reference(name):
+    g, plan, P = sd_case(name)
+    out = sd_nets.sd_unet_forward(P, plan, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]),
+                                  torch.from_numpy(g["context"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=2e-4, atol=2e-5)
+
+
+def test_sd_v1_plan_matches_the_published_architecture():
+    plan = sd_unet_plan(**SD_V1)
+    shapes = plan.param_shapes()
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 859_520_964  # SD v1 UNet (859.5 M)
+    assert len(plan.input_blocks) == 12 and len(plan.output_blocks) == 12
+    heads = {(b.heads, b.d_head) for b in plan.all_blocks() if hasattr(b, "d_head")}
+    assert heads == {(8, 40), (8, 80), (8, 160)}
+    assert shapes["input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight"] == (320, 768)
+    assert shapes["output_blocks.2.1.conv.weight"] == (1280, 1280, 3, 3)
+    assert shapes["output_blocks.5.2.conv.weight"] == (1280, 1280, 3, 3)
