@@ -77,6 +77,10 @@ SIGNATURES = {
     "adm_pool_attn_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_pool_prep_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "adm_pack_conv_weight_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "adm_attention_cross": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "adm_layernorm": (_I, [_P, _P, _P, _P, C.c_int64, _I, _F, _P]),
+    "adm_geglu": (_I, [_P, _P, C.c_int64, _I, _P]),
+    "adm_gn_finalize_add": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
     "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
 }
 

@@ -25,8 +25,10 @@ constexpr int PADE = 16;      // bf16 elements of row padding: row stride = D/2 
 
 struct AttnK {
   const uint16_t* qkv; uint16_t* out; float* lse;
-  int T, heads, C3, C;
-  int q_off, k_off, v_off, head_stride;
+  const uint16_t* kv;      // keys / values: [N][kv_rows][Ckv], the first Tk rows of an image are attended to
+  int T, heads, C3, C;     // T queries per image, row pitch C3 of the query tensor, C = heads * D output columns
+  int Tk, kv_rows, Ckv;
+  int q_off, k_off, v_off, head_stride, kv_head_stride;
   float scale_log2;  // log2(e) / sqrt(D)
 };
 
@@ -50,8 +52,10 @@ attn_kernel(const AttnK p) {
   const int n = by / p.heads, hd = by % p.heads;
   const int qbase = bx * QB + wave * QW;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
-  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
-            vcol = p.v_off + hd * p.head_stride;
+  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.kv_head_stride,
+            vcol = p.v_off + hd * p.kv_head_stride;
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kv + (long long)n * p.kv_rows * p.Ckv), 0,
+                                                                       p.Tk * p.Ckv * 2, 0x00020000);
 
   // one descriptor over this image's T rows: queries / keys beyond T read as zeros (no bounds branches)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
@@ -75,20 +79,20 @@ attn_kernel(const AttnK p) {
   float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
 
   AdmTileRegs<KT, D, 256> kr, vr;
-  kr.load_buf(rs, p.C3, kcol, 0, tid);
-  vr.load_buf(rs, p.C3, vcol, 0, tid);
+  kr.load_buf(rsk, p.Ckv, kcol, 0, tid);
+  vr.load_buf(rsk, p.Ckv, vcol, 0, tid);
   kr.store(Ks[0], KROW, tid);
   vr.store(Vs[0], KROW, tid);
   __syncthreads();
 
-  const int ntiles = (p.T + KT - 1) / KT;
+  const int ntiles = (p.Tk + KT - 1) / KT;
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int k0 = kt0 * KT;
     const int cur = kt0 & 1;
     const bool next = kt0 + 1 < ntiles;
     if (next) {
-      kr.load_buf(rs, p.C3, kcol, k0 + KT, tid);
-      vr.load_buf(rs, p.C3, vcol, k0 + KT, tid);
+      kr.load_buf(rsk, p.Ckv, kcol, k0 + KT, tid);
+      vr.load_buf(rsk, p.Ckv, vcol, k0 + KT, tid);
     }
     const uint16_t* Kc = Ks[cur];
     const uint16_t* Vc = Vs[cur];
@@ -126,7 +130,7 @@ attn_kernel(const AttnK p) {
       for (int kb = 0; kb < 2; ++kb) vfr[dt][kb] = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
     __builtin_amdgcn_sched_barrier(0);
     // ---- online softmax (per query column)
-    const bool ragged = k0 + KT > p.T;
+    const bool ragged = k0 + KT > p.Tk;
     bf16x8 pf[2][2];  // [query tile][32-key block]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -137,7 +141,7 @@ attn_kernel(const AttnK p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (k0 + kt * 16 + lq * 4 + r >= p.T) st[kt][qt][r] = -1e30f;
+            if (k0 + kt * 16 + lq * 4 + r >= p.Tk) st[kt][qt][r] = -1e30f;
       }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -231,8 +235,10 @@ attn_wide_kernel(const AttnK p) {
   const int n = by / p.heads, hd = by % p.heads;
   const int q = bx * QB2 + wave * 16 + lc;
   const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
-  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.head_stride,
-            vcol = p.v_off + hd * p.head_stride;
+  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.kv_head_stride,
+            vcol = p.v_off + hd * p.kv_head_stride;
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kv + (long long)n * p.kv_rows * p.Ckv), 0,
+                                                                       p.Tk * p.Ckv * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
 
   bf16x8 qf[KS];
@@ -247,11 +253,11 @@ attn_wide_kernel(const AttnK p) {
   float m_run = -1e30f, l_run = 0.f;
 
   AdmTileRegs<KT2, D, 256> kr, vr;
-  const int ntiles = (p.T + KT2 - 1) / KT2;
+  const int ntiles = (p.Tk + KT2 - 1) / KT2;
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int k0 = kt0 * KT2;
-    kr.load_buf(rs, p.C3, kcol, k0, tid);
-    vr.load_buf(rs, p.C3, vcol, k0, tid);
+    kr.load_buf(rsk, p.Ckv, kcol, k0, tid);
+    vr.load_buf(rsk, p.Ckv, vcol, k0, tid);
     __syncthreads();  // the previous tile's readers are done
     kr.store(Ks, KROW, tid);
     vr.store(Vs, KROW, tid);
@@ -267,12 +273,12 @@ attn_wide_kernel(const AttnK p) {
         st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[kt], 0, 0, 0);
       }
     }
-    if (k0 + KT2 > p.T) {
+    if (k0 + KT2 > p.Tk) {
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (k0 + kt * 16 + lq * 4 + r >= p.T) st[kt][r] = -1e30f;
+          if (k0 + kt * 16 + lq * 4 + r >= p.Tk) st[kt][r] = -1e30f;
     }
     float mx = -1e30f;
 #pragma unroll
@@ -317,6 +323,8 @@ attn_wide_kernel(const AttnK p) {
   }
 }
 
+int launch_attention(const AttnK& k, int n, int t, int heads, int d, hipStream_t s);
+
 }  // namespace
 
 extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int t, int heads, int d,
@@ -340,9 +348,37 @@ extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse,
   k.C = heads * d; k.C3 = 3 * k.C;
   if (new_order) { k.q_off = 0; k.k_off = k.C; k.v_off = 2 * k.C; k.head_stride = d; }
   else           { k.q_off = 0; k.k_off = d;   k.v_off = 2 * d;   k.head_stride = 3 * d; }
+  k.kv = qkv; k.Tk = t; k.kv_rows = t; k.Ckv = k.C3; k.kv_head_stride = k.head_stride;
   k.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+  return launch_attention(k, n, t, heads, d, (hipStream_t)stream);
+}
+
+extern "C" int adm_attention_cross(const adm_bf16* q, int q_stride, const adm_bf16* kv, int kv_stride, int kv_rows,
+                                   adm_bf16* out, int n, int tq, int tk, int heads, int d, float scale, void* stream) {
+  ADM_REQUIRE(q && kv && out, ADM_E_ARG, "adm_attention_cross: null pointer");
+  ADM_REQUIRE(n > 0 && tq > 0 && tk > 0 && heads > 0 && kv_rows >= tk, ADM_E_ARG,
+              "adm_attention_cross: bad shape n=%d tq=%d tk=%d kv_rows=%d heads=%d", n, tq, tk, kv_rows, heads);
+  ADM_REQUIRE(d == 32 || d == 64 || d == 128 || d == 192 || d == 256, ADM_E_SHAPE,
+              "adm_attention_cross: head dim %d unsupported (32, 64, 128, 192, 256)", d);
+  ADM_REQUIRE(q_stride >= heads * d && kv_stride >= 2 * heads * d && q_stride % 8 == 0 && kv_stride % 8 == 0, ADM_E_SHAPE,
+              "adm_attention_cross: row pitches %d / %d too small or not multiples of 8", q_stride, kv_stride);
+  ADM_REQUIRE(adm_aligned16(q) && adm_aligned16(kv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention_cross: unaligned pointer");
+  ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention_cross: n*heads exceeds grid.y");
+  ADM_REQUIRE((long long)tq * q_stride < (1ll << 30) && (long long)tk * kv_stride < (1ll << 30), ADM_E_SHAPE,
+              "adm_attention_cross: an image's rows exceed the 32-bit byte offsets of a buffer descriptor");
+  AttnK k{};
+  k.qkv = q; k.out = out; k.lse = nullptr; k.T = tq; k.heads = heads;
+  k.C = heads * d; k.C3 = q_stride;
+  k.q_off = 0; k.head_stride = d;
+  k.kv = kv; k.Tk = tk; k.kv_rows = kv_rows; k.Ckv = kv_stride;
+  k.k_off = 0; k.v_off = heads * d; k.kv_head_stride = d;
+  k.scale_log2 = 1.4426950408889634f * (scale > 0.f ? scale : 1.0f / sqrtf((float)d));
+  return launch_attention(k, n, tq, heads, d, (hipStream_t)stream);
+}
+
+namespace {
+int launch_attention(const AttnK& k, int n, int t, int heads, int d, hipStream_t s) {
   dim3 grid((t + QB - 1) / QB, n * heads);
-  hipStream_t s = (hipStream_t)stream;
   if (d > 128) {
     dim3 gridw((t + 63) / 64, n * heads);
     if (d == 192) hipLaunchKernelGGL((attn_wide_kernel<192>), gridw, dim3(256), 0, s, k);
@@ -354,3 +390,4 @@ extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse,
   else hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, k);
   return adm_check_launch("adm_attention");
 }
+}  // namespace

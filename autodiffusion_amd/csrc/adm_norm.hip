@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256)
 gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const float* __restrict__ part1, int c1, int slabs1,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
                    const float* __restrict__ film, int film_stride, float* __restrict__ aff_a,
-                   float* __restrict__ aff_b, float* __restrict__ stats, int hw, float eps) {
+                   float* __restrict__ aff_b, float* __restrict__ stats, int hw, float eps,
+                   const float* __restrict__ add, int add_stride) {
   const int c = c0 + c1;
   __shared__ float gmean[32], grstd[32];
   const int img = blockIdx.x;
@@ -142,11 +143,19 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
     const bool first = ch < c0;
     const float* base = first ? part0 : part1;
     const int cs = first ? c0 : c1, cl = first ? ch : ch - c0, slabs = first ? slabs0 : slabs1;
+    double cs1 = 0.0, cs2 = 0.0;
     for (int sl = 0; sl < slabs; ++sl) {
       const float* p = base + ((((long long)img * slabs + sl) * cs) + cl) * 2;
-      s += (double)p[0];
-      ss += (double)p[1];
+      cs1 += (double)p[0];
+      cs2 += (double)p[1];
     }
+    if (add) {  // statistics of x + e[img, ch] from those of x: sum += hw*e, sum of squares += 2*e*sum + hw*e^2
+      const double e = (double)add[(long long)img * add_stride + ch];
+      cs2 += 2.0 * e * cs1 + (double)hw * e * e;
+      cs1 += (double)hw * e;
+    }
+    s += cs1;
+    ss += cs2;
   }
 #pragma unroll
   for (int off = 4; off >= 1; off >>= 1) {
@@ -170,6 +179,7 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
     const int g = ch / cpg;
     float a = grstd[g] * gamma[ch];
     float b = beta[ch] - gmean[g] * a;
+    if (add) b += a * add[(long long)img * add_stride + ch];  // y = a*(x + e) + b applied to the stored x
     if (film) {
       const float sc = 1.0f + film[(long long)img * film_stride + ch];
       const float sh = film[(long long)img * film_stride + c + ch];
@@ -182,11 +192,11 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
 }
 
 // ------------------------------------------------------------------------------------ resample
-template <int MODE, bool ACT>  // MODE 1: avgpool2, 2: nearest x2
+template <int MODE, bool ACT>  // MODE 1: avgpool2, 2: nearest x2, 3: every second pixel (stride-2 subsample)
 __global__ void __launch_bounds__(256)
 resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a, const float* __restrict__ aff_b,
                 uint16_t* __restrict__ out, int n, int h, int w, int c) {
-  const int oh = MODE == 1 ? h / 2 : h * 2, ow = MODE == 1 ? w / 2 : w * 2;
+  const int oh = MODE == 2 ? h * 2 : h / 2, ow = MODE == 2 ? w * 2 : w / 2;
   const int cg = c / 8;
   const long long items = (long long)n * oh * ow * cg;
   for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
@@ -205,8 +215,8 @@ resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a
     constexpr int TAPS = MODE == 1 ? 4 : 1;
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
-      const int iy = MODE == 1 ? oy * 2 + tp / 2 : oy / 2;
-      const int ix = MODE == 1 ? ox * 2 + tp % 2 : ox / 2;
+      const int iy = MODE == 1 ? oy * 2 + tp / 2 : (MODE == 2 ? oy / 2 : oy * 2);
+      const int ix = MODE == 1 ? ox * 2 + tp % 2 : (MODE == 2 ? ox / 2 : ox * 2);
       const uint4 v = *reinterpret_cast<const uint4*>(in + (((long long)img * h + iy) * w + ix) * c + g * 8);
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -283,8 +293,20 @@ extern "C" int adm_gn_finalize(const float* partial, const float* gamma, const f
   ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0, ADM_E_SHAPE, "adm_gn_finalize: bad shape");
   ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize: film_stride < 2*c");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
-                     (const float*)nullptr, 0, 0, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps);
+                     (const float*)nullptr, 0, 0, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps,
+                     (const float*)nullptr, 0);
   return adm_check_launch("adm_gn_finalize");
+}
+
+extern "C" int adm_gn_finalize_add(const float* partial, const float* gamma, const float* beta, const float* add,
+                                   int add_stride, float* aff_a, float* aff_b, int n, int c, int hw, int slabs, float eps,
+                                   void* stream) {
+  ADM_REQUIRE(partial && gamma && beta && add && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize_add: null pointer");
+  ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0 && add_stride >= c, ADM_E_SHAPE, "adm_gn_finalize_add: bad shape");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
+                     (const float*)nullptr, 0, 0, gamma, beta, (const float*)nullptr, 0, aff_a, aff_b, (float*)nullptr, hw, eps,
+                     add, add_stride);
+  return adm_check_launch("adm_gn_finalize_add");
 }
 
 extern "C" int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const float* partial1, int c1, int slabs1,
@@ -297,7 +319,7 @@ extern "C" int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const
               "adm_gn_finalize2: bad shape");
   ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize2: film_stride < 2*c");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial0, c0, slabs0, partial1, c1,
-                     slabs1, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps);
+                     slabs1, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps, (const float*)nullptr, 0);
   return adm_check_launch("adm_gn_finalize2");
 }
 
@@ -305,12 +327,12 @@ extern "C" int adm_resample(const adm_bf16* in, const float* aff_a, const float*
                             int w, int c, int mode, void* stream) {
   ADM_REQUIRE(in && out, ADM_E_ARG, "adm_resample: null pointer");
   ADM_REQUIRE((aff_a != nullptr) == (aff_b != nullptr), ADM_E_ARG, "adm_resample: aff_a/aff_b go together");
-  ADM_REQUIRE(mode == 1 || mode == 2, ADM_E_ARG, "adm_resample: mode must be 1 (avgpool2) or 2 (nearest x2)");
+  ADM_REQUIRE(mode >= 1 && mode <= 3, ADM_E_ARG, "adm_resample: mode must be 1 (avgpool2), 2 (nearest x2) or 3 (stride-2 subsample)");
   ADM_REQUIRE(n > 0 && h > 0 && w > 0 && c % 8 == 0, ADM_E_SHAPE, "adm_resample: bad shape");
-  ADM_REQUIRE(mode != 1 || (h % 2 == 0 && w % 2 == 0), ADM_E_SHAPE, "adm_resample: odd size for avgpool2");
+  ADM_REQUIRE(mode == 2 || (h % 2 == 0 && w % 2 == 0), ADM_E_SHAPE, "adm_resample: odd size for a 2x reduction");
   ADM_REQUIRE(adm_aligned16(in) && adm_aligned16(out) && adm_aligned16(aff_a) && adm_aligned16(aff_b), ADM_E_ALIGN,
               "adm_resample: unaligned pointer");
-  const int oh = mode == 1 ? h / 2 : h * 2, ow = mode == 1 ? w / 2 : w * 2;
+  const int oh = mode == 2 ? h * 2 : h / 2, ow = mode == 2 ? w * 2 : w / 2;
   const long long items = (long long)n * oh * ow * (c / 8);
   int blocks = (int)((items + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -318,7 +340,8 @@ extern "C" int adm_resample(const adm_bf16* in, const float* aff_a, const float*
   const bool act = aff_a != nullptr;
 #define LAUNCH(M, A) hipLaunchKernelGGL((resample_kernel<M, A>), dim3(blocks), dim3(256), 0, s, in, aff_a, aff_b, out, n, h, w, c)
   if (mode == 1) { if (act) LAUNCH(1, true); else LAUNCH(1, false); }
-  else           { if (act) LAUNCH(2, true); else LAUNCH(2, false); }
+  else if (mode == 2) { if (act) LAUNCH(2, true); else LAUNCH(2, false); }
+  else           { if (act) LAUNCH(3, true); else LAUNCH(3, false); }
 #undef LAUNCH
   return adm_check_launch("adm_resample");
 }

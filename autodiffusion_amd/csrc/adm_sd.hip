@@ -1,0 +1,128 @@
+// Token-wise kernels of the Stable-Diffusion SpatialTransformer (gfx950): LayerNorm and GEGLU over bf16
+// [rows][C] token tensors (rows = images x pixels; in NHWC a token IS a pixel, so the Linear layers around them
+// are adm_conv 1x1 launches).  Both are single-pass HBM streams: 16-byte lanes, fp32 math.
+// Reference: "Stable Diffusion"/ldm/modules/attention.py:196-215 (BasicTransformerBlock), 36-44 (GEGLU).
+#include "adm_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 v, float* f) {
+  const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(u[j] << 16);
+    f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+  }
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 pk;
+  pk.x = adm_f32_to_bf16(f[0]) | ((uint32_t)adm_f32_to_bf16(f[1]) << 16);
+  pk.y = adm_f32_to_bf16(f[2]) | ((uint32_t)adm_f32_to_bf16(f[3]) << 16);
+  pk.z = adm_f32_to_bf16(f[4]) | ((uint32_t)adm_f32_to_bf16(f[5]) << 16);
+  pk.w = adm_f32_to_bf16(f[6]) | ((uint32_t)adm_f32_to_bf16(f[7]) << 16);
+  return pk;
+}
+
+// One wave per token row; the row stays in registers between the mean, the variance (two-pass, as
+// torch.nn.LayerNorm computes it) and the normalised store.  SEGS = 16-byte segments per lane (C <= 512 * SEGS).
+template <int SEGS>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                 uint16_t* __restrict__ out, long long rows, int c, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nseg = c / 8;
+  const float inv_c = 1.0f / (float)c;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    float v[SEGS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEGS; ++i) {
+      const int sg = lane + i * 64;
+      if (sg < nseg) {
+        unpack8(*reinterpret_cast<const uint4*>(x + row * c + sg * 8), v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+      }
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < SEGS; ++i)
+      if (lane + i * 64 < nseg) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = v[i][j] - mean;
+          ss += d * d;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(ss) * inv_c + eps);
+#pragma unroll
+    for (int i = 0; i < SEGS; ++i) {
+      const int sg = lane + i * 64;
+      if (sg < nseg) {
+        float g8[8], b8[8], y[8];
+        *reinterpret_cast<float4*>(g8) = *reinterpret_cast<const float4*>(gamma + sg * 8);
+        *reinterpret_cast<float4*>(g8 + 4) = *reinterpret_cast<const float4*>(gamma + sg * 8 + 4);
+        *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(beta + sg * 8);
+        *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(beta + sg * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (v[i][j] - mean) * rstd * g8[j] + b8[j];
+        *reinterpret_cast<uint4*>(out + row * c + sg * 8) = pack8(y);
+      }
+    }
+  }
+}
+
+// out[r][i] = u[r][i] * gelu(u[r][inner + i]), exact (erf) GELU as F.gelu's default
+__global__ void __launch_bounds__(256)
+geglu_kernel(const uint16_t* __restrict__ u, uint16_t* __restrict__ out, long long rows, int inner) {
+  const int sg = inner / 8;
+  const long long items = rows * sg;
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
+    const long long r = it / sg;
+    const int i = (int)(it % sg);
+    float a[8], g[8], y[8];
+    unpack8(*reinterpret_cast<const uint4*>(u + r * 2 * inner + i * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(u + r * 2 * inner + inner + i * 8), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = a[j] * (0.5f * g[j] * (1.0f + erff(g[j] * 0.70710678118654752f)));
+    *reinterpret_cast<uint4*>(out + r * inner + i * 8) = pack8(y);
+  }
+}
+
+}  // namespace
+
+extern "C" int adm_layernorm(const adm_bf16* x, const float* gamma, const float* beta, adm_bf16* out, int64_t rows,
+                             int c, float eps, void* stream) {
+  ADM_REQUIRE(x && gamma && beta && out, ADM_E_ARG, "adm_layernorm: null pointer");
+  ADM_REQUIRE(rows > 0 && c > 0 && c % 8 == 0 && c <= 2048, ADM_E_SHAPE, "adm_layernorm: rows=%lld c=%d unsupported (c %% 8 == 0, c <= 2048)",
+              (long long)rows, c);
+  ADM_REQUIRE(adm_aligned16(x) && adm_aligned16(out) && adm_aligned16(gamma) && adm_aligned16(beta), ADM_E_ALIGN,
+              "adm_layernorm: unaligned pointer");
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  const int segs = (c / 8 + 63) / 64;
+  if (segs <= 1) hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, out, (long long)rows, c, eps);
+  else if (segs == 2) hipLaunchKernelGGL((layernorm_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, out, (long long)rows, c, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, out, (long long)rows, c, eps);
+  return adm_check_launch("adm_layernorm");
+}
+
+extern "C" int adm_geglu(const adm_bf16* u, adm_bf16* out, int64_t rows, int inner, void* stream) {
+  ADM_REQUIRE(u && out, ADM_E_ARG, "adm_geglu: null pointer");
+  ADM_REQUIRE(rows > 0 && inner > 0 && inner % 8 == 0, ADM_E_SHAPE, "adm_geglu: rows=%lld inner=%d unsupported", (long long)rows, inner);
+  ADM_REQUIRE(adm_aligned16(u) && adm_aligned16(out), ADM_E_ALIGN, "adm_geglu: unaligned pointer");
+  const long long items = (long long)rows * (inner / 8);
+  long long blocks = (items + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, out, (long long)rows, inner);
+  return adm_check_launch("adm_geglu");
+}

@@ -117,12 +117,15 @@ def gn_slabs(hw: int) -> int:
     return max(1, min(64, hw // 64))
 
 
-def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, want_stats=False):
+def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, want_stats=False, eps=None, add=None):
     """GroupNorm32 statistics of the virtual concat (x0 | x1) -> per-(image, channel) affine (a, b).
 
     film: fp32 view whose row n, columns [0:C) = scale and [C:2C) = shift (row stride film_stride).
     want_stats: also return fp32 [N, 32, 2] (mean, rstd) for the backward-data pass.
+    eps: GroupNorm epsilon (default GroupNorm32's 1e-5; the SpatialTransformer's Normalize uses 1e-6).
+    add: fp32 [N, C]: the affine is that of GroupNorm(x0 + add[:, :, None, None]) applied to the stored x0.
     """
+    eps = GN_EPS if eps is None else float(eps)
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     c, hw = c0 + c1, h * w
@@ -137,12 +140,27 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
     stats = torch.empty((n, 32, 2), dtype=torch.float32, device=x0.device) if want_stats else None
     fused0 = getattr(x0, "_adm_stats", None)
     fused1 = getattr(x1, "_adm_stats", None) if x1 is not None else None
+    if add is not None:
+        if x1 is not None or film is not None or want_stats:
+            raise AdmError("gn_affine(add=...) takes one source, no FiLM and keeps no statistics")
+        if add.dtype != torch.float32 or add.shape != (n, c) or add.stride(1) != 1:
+            raise AdmError("add must be float32 [N, C] with unit channel stride")
+        if USE_FUSED_STATS and fused0 is not None:
+            part, slabs = fused0
+        else:
+            slabs = gn_slabs(hw)
+            part = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
+            check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, None, 0, _ptr(part), n, hw, slabs, _stream()), "adm_gn_partial")
+        check(lib.adm_gn_finalize_add(_ptr(part), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+                                      add.data_ptr(), add.stride(0), _ptr(a), _ptr(b), n, c, hw, slabs, eps, _stream()),
+              "adm_gn_finalize_add")
+        return a, b
     if USE_FUSED_STATS and fused0 is not None and (x1 is None or fused1 is not None):
         # the producing conv already accumulated sum / sum-of-squares of this tensor in its epilogue
         p1, s1 = (fused1 if fused1 is not None else (None, 0))
         check(lib.adm_gn_finalize2(_ptr(fused0[0]), c0, fused0[1], _ptr(p1), c1, s1, _ptr(gamma, torch.float32, "gamma"),
                                    _ptr(beta, torch.float32, "beta"), film_ptr, film_stride, _ptr(a), _ptr(b),
-                                   _ptr(stats), n, hw, GN_EPS, _stream()), "adm_gn_finalize2")
+                                   _ptr(stats), n, hw, eps, _stream()), "adm_gn_finalize2")
     else:
         slabs = gn_slabs(hw)
         if partial is None:
@@ -150,7 +168,7 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
         check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, _ptr(x1, BF16, "x1"), c1, _ptr(partial), n, hw, slabs,
                                  _stream()), "adm_gn_partial")
         check(lib.adm_gn_finalize(_ptr(partial), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
-                                  film_ptr, film_stride, _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, GN_EPS,
+                                  film_ptr, film_stride, _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, eps,
                                   _stream()), "adm_gn_finalize")
     if want_stats:
         return a, b, stats
@@ -158,10 +176,11 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
 
 
 def resample(x, mode: str, aff=None):
-    """mode 'down' = AvgPool2d(2), 'up' = nearest x2; aff=(a, b) applies SiLU(a*x+b) first."""
+    """mode 'down' = AvgPool2d(2), 'up' = nearest x2, 'stride2' = every second pixel; aff=(a, b) applies
+    SiLU(a*x+b) first."""
     n, h, w, c = x.shape
-    m = {"down": 1, "up": 2}[mode]
-    oh, ow = (h // 2, w // 2) if m == 1 else (h * 2, w * 2)
+    m = {"down": 1, "up": 2, "stride2": 3}[mode]
+    oh, ow = (h * 2, w * 2) if m == 2 else (h // 2, w // 2)
     out = torch.empty((n, oh, ow, c), dtype=BF16, device=x.device)
     a, b = aff if aff is not None else (None, None)
     check(_lib.load().adm_resample(_ptr(x, BF16, "x"), _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(out),
@@ -269,6 +288,40 @@ def attention(qkv, heads: int, new_order: bool, want_lse: bool = False):
     check(_lib.load().adm_attention_lse(_ptr(qkv, BF16, "qkv"), _ptr(out), _ptr(lse), n, t, heads, d,
                                         int(new_order), _stream()), "adm_attention")
     return (out, lse) if want_lse else out
+
+
+def attention_cross(q, kv, heads: int, d: int, tk: int, scale: float, q_cols: int = None):
+    """q bf16 [N, Tq, >= H*D] (head h at columns h*D), kv bf16 [N, rows >= tk, >= 2*H*D] (K heads, then V heads)
+    -> bf16 [N, Tq, H*D] = softmax(q k^T * scale) v over the first tk rows of kv.  kv may alias q's storage
+    (self-attention over a fused [q | k | v] projection: pass kv = qkv[:, :, H*D:])."""
+    n, tq, _ = q.shape
+    if q.stride(2) != 1 or kv.stride(2) != 1 or q.stride(0) != tq * q.stride(1) or kv.stride(0) != kv.shape[1] * kv.stride(1):
+        raise AdmError("attention_cross: q / kv must be row-major with dense image pitch")
+    out = torch.empty((n, tq, heads * d), dtype=BF16, device=q.device)
+    for t_ in (q, kv):
+        if t_.dtype != BF16 or not t_.is_cuda:
+            raise AdmError("attention_cross: bf16 device tensors required")
+    check(_lib.load().adm_attention_cross(q.data_ptr(), q.stride(1), kv.data_ptr(), kv.stride(1), kv.shape[1],
+                                          _ptr(out), n, tq, tk, heads, d, float(scale), _stream()), "adm_attention_cross")
+    return out
+
+
+# ------------------------------------------------------------------ Stable-Diffusion token kernels
+def layernorm(x, gamma, beta, eps: float = 1e-5):
+    """bf16 [..., C] -> bf16, LayerNorm over the last dimension (fp32 statistics)."""
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    check(_lib.load().adm_layernorm(_ptr(x, BF16, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+                                    _ptr(out), x.numel() // c, c, float(eps), _stream()), "adm_layernorm")
+    return out
+
+
+def geglu(u):
+    """bf16 [..., 2*I] -> bf16 [..., I]: u[..., :I] * gelu(u[..., I:])."""
+    inner = u.shape[-1] // 2
+    out = torch.empty(u.shape[:-1] + (inner,), dtype=BF16, device=u.device)
+    check(_lib.load().adm_geglu(_ptr(u, BF16, "u"), _ptr(out), u.numel() // (2 * inner), inner, _stream()), "adm_geglu")
+    return out
 
 
 # ------------------------------------------------------------------ backward-data (classifier guidance)

@@ -1,0 +1,257 @@
+"""Stable-Diffusion latent UNet forward on hand-written HIP kernels.
+
+Host-side mirror of ``ldm.modules.diffusionmodules.openaimodel.UNetModel`` (reference "Stable Diffusion"/ldm/modules/
+diffusionmodules/openaimodel.py:413-742) in the form the reference's configs instantiate (v1-inference*.yaml:
+``use_spatial_transformer``, conv resampling, no scale-shift norm): same constructor arguments, the same state-dict
+keys (an SD-v1 ``model.diffusion_model.*`` checkpoint loads unchanged), ``__call__(x, timesteps, context)`` taking and
+returning fp32 NCHW latents.
+
+Engine: activations are bf16 NHWC, so a token of the SpatialTransformer IS a pixel and every Linear is an ``adm_conv``
+1x1 launch.  Per block:
+  ResBlock (openaimodel.py:236-262)   gn -> conv3x3[affine+SiLU] -> gn of (h + emb) folded into the affine
+                                      (adm_gn_finalize_add: h + emb is never written) -> conv3x3[affine+SiLU, +skip]
+  Downsample (:118-145)               stride-1 conv3x3 + every-second-pixel pick (first build: 4x the MACs of 3 layers)
+  Upsample (:78-104)                  conv3x3 reading its input through the virtual nearest 2x upsample (in_up)
+  SpatialTransformer (attention.py:218-260)
+      gn(eps 1e-6) -> 1x1 proj_in [affine prologue]
+      LayerNorm -> fused q|k|v 1x1 -> attention -> 1x1 to_out (+x)
+      LayerNorm -> 1x1 to_q; context -> 1x1 k|v (77 tokens padded to a 8x16 map) -> attention -> 1x1 to_out (+x)
+      LayerNorm -> 1x1 (C -> 8C) -> GEGLU -> 1x1 (4C -> C) (+x);  1x1 proj_out (+x_in)
+  The reference's 40 / 80 / 160-channel heads are zero-padded to 64 / 128 / 192 by the packed projection weights (the
+  MFMA attention kernels take head widths 32/64/128/192/256); the logit scale stays dim_head^-0.5.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from ._lib import AdmError
+from .sd_arch import (SDDownSpec, SDResBlockSpec, SDStemSpec, SDTransformerSpec, SDUNetPlan, SDUpSpec,
+                      sd_unet_plan)
+from .unet import HipModule, _Prep
+
+_HEAD_WIDTHS = (32, 64, 128, 192, 256)
+
+
+def _padded_head(d: int) -> int:
+    for w in _HEAD_WIDTHS:
+        if d <= w:
+            return w
+    raise NotImplementedError(f"attention heads of {d} channels exceed the widest kernel (256)")
+
+
+def _pad_heads_out(w: torch.Tensor, heads: int, d: int, dp: int) -> torch.Tensor:
+    """Linear weight [heads*d, cin] -> [heads*dp, cin]: every head's output rows zero-padded to dp."""
+    cin = w.shape[1]
+    out = torch.zeros((heads, dp, cin), dtype=torch.float32, device=w.device)
+    out[:, :d] = w.to(torch.float32).reshape(heads, d, cin)
+    return out.reshape(heads * dp, cin)
+
+
+def _pad_heads_in(w: torch.Tensor, heads: int, d: int, dp: int) -> torch.Tensor:
+    """Linear weight [cout, heads*d] -> [cout, heads*dp]: zero columns where the padded head channels arrive."""
+    cout = w.shape[0]
+    out = torch.zeros((cout, heads, dp), dtype=torch.float32, device=w.device)
+    out[:, :, :d] = w.to(torch.float32).reshape(cout, heads, d)
+    return out.reshape(cout, heads * dp)
+
+
+class UNetModel(HipModule):
+    def __init__(self, image_size=None, in_channels=4, model_channels=320, out_channels=4, num_res_blocks=2,
+                 attention_resolutions=(4, 2, 1), dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1, context_dim=None,
+                 n_embed=None, legacy=True):
+        unsupported = dict(conv_resample=not conv_resample, dims=dims != 2, num_classes=num_classes is not None,
+                           use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
+                           use_spatial_transformer=not use_spatial_transformer, n_embed=n_embed is not None,
+                           num_heads_upsample=num_heads_upsample not in (-1, num_heads))
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"latent UNet on the HIP path: unsupported constructor arguments {bad} "
+                                      "(built: the v1-inference configuration family)")
+        plan = sd_unet_plan(in_channels, model_channels, out_channels, num_res_blocks, tuple(attention_resolutions),
+                            tuple(channel_mult), num_heads, num_head_channels, transformer_depth,
+                            int(context_dim) if not isinstance(context_dim, (list, tuple)) else int(context_dim[0]),
+                            legacy)
+        super().__init__(plan, use_fp16)
+        self.image_size = image_size
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_classes = None
+
+    @staticmethod
+    def _init_param(name, shape, g):
+        if name.endswith(("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias")) \
+                or name in ("out.2.weight", "out.2.bias"):
+            return torch.zeros(shape)  # zero_module (openaimodel.py:224-226, 703; attention.py:241-245)
+        return HipModule._init_param(name, shape, g)
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self):
+        P, dev, plan = self._params, self.device, self.plan
+        if dev.type != "cuda":
+            raise AdmError("latent UNetModel: parameters are on the CPU; call .to(device) first (no CPU fallback)")
+        pr = _Prep()
+        f32 = lambda k: P[k].to(torch.float32).contiguous()  # noqa: E731
+        pack = ops.pack_conv_weight
+        pr.te0_w, pr.te0_b = f32("time_embed.0.weight"), f32("time_embed.0.bias")
+        pr.te2_w, pr.te2_b = f32("time_embed.2.weight"), f32("time_embed.2.bias")
+        ws, bs, off = [], [], 0
+        pr.emb_off: Dict[str, int] = {}
+        pr.blocks: Dict[str, dict] = {}
+        zmax = 0
+        for b in plan.all_blocks():
+            p = b.prefix
+            if isinstance(b, SDStemSpec):
+                wpad = torch.zeros((b.cout, 32, 3, 3), dtype=torch.float32, device=dev)
+                wpad[:, :b.cin] = P[f"{p}.weight"].to(torch.float32)
+                pr.blocks[p] = dict(w=pack(wpad), b=f32(f"{p}.bias"))
+            elif isinstance(b, SDResBlockSpec):
+                ws.append(f32(f"{p}.emb_layers.1.weight"))
+                bs.append(f32(f"{p}.emb_layers.1.bias"))
+                pr.emb_off[p] = off
+                off += b.cout
+                d = dict(g1=f32(f"{p}.in_layers.0.weight"), b1=f32(f"{p}.in_layers.0.bias"),
+                         w1=pack(P[f"{p}.in_layers.2.weight"]), c1b=f32(f"{p}.in_layers.2.bias"),
+                         g2=f32(f"{p}.out_layers.0.weight"), b2=f32(f"{p}.out_layers.0.bias"),
+                         w2=pack(P[f"{p}.out_layers.3.weight"]), c2b=f32(f"{p}.out_layers.3.bias"))
+                if b.has_skip_conv:
+                    d["ws"] = pack(P[f"{p}.skip_connection.weight"])
+                    d["wsb"] = f32(f"{p}.skip_connection.bias")
+                pr.blocks[p] = d
+            elif isinstance(b, SDDownSpec):
+                pr.blocks[p] = dict(w=pack(P[f"{p}.op.weight"]), b=f32(f"{p}.op.bias"))
+            elif isinstance(b, SDUpSpec):
+                pr.blocks[p] = dict(w=pack(P[f"{p}.conv.weight"]), b=f32(f"{p}.conv.bias"))
+            elif isinstance(b, SDTransformerSpec):
+                h, dh, dp = b.heads, b.d_head, _padded_head(b.d_head)
+                d = dict(g=f32(f"{p}.norm.weight"), b=f32(f"{p}.norm.bias"), dp=dp,
+                         w_in=pack(P[f"{p}.proj_in.weight"]), b_in=f32(f"{p}.proj_in.bias"),
+                         w_out=pack(P[f"{p}.proj_out.weight"]), b_out=f32(f"{p}.proj_out.bias"), layers=[])
+                zmax = max(zmax, 3 * h * dp)
+                for li in range(b.depth):
+                    q = f"{p}.transformer_blocks.{li}"
+                    L = {}
+                    for k in ("norm1", "norm2", "norm3"):
+                        L[k] = (f32(f"{q}.{k}.weight"), f32(f"{q}.{k}.bias"))
+                    L["qkv1"] = pack(torch.cat([_pad_heads_out(P[f"{q}.attn1.to_{c}.weight"], h, dh, dp) for c in "qkv"]))
+                    L["o1"] = pack(_pad_heads_in(P[f"{q}.attn1.to_out.0.weight"], h, dh, dp))
+                    L["o1b"] = f32(f"{q}.attn1.to_out.0.bias")
+                    L["q2"] = pack(_pad_heads_out(P[f"{q}.attn2.to_q.weight"], h, dh, dp))
+                    L["kv2"] = pack(torch.cat([_pad_heads_out(P[f"{q}.attn2.to_{c}.weight"], h, dh, dp) for c in "kv"]))
+                    L["o2"] = pack(_pad_heads_in(P[f"{q}.attn2.to_out.0.weight"], h, dh, dp))
+                    L["o2b"] = f32(f"{q}.attn2.to_out.0.bias")
+                    L["ff1"] = pack(P[f"{q}.ff.net.0.proj.weight"])
+                    L["ff1b"] = f32(f"{q}.ff.net.0.proj.bias")
+                    L["ff2"] = pack(P[f"{q}.ff.net.2.weight"])
+                    L["ff2b"] = f32(f"{q}.ff.net.2.bias")
+                    d["layers"].append(L)
+                pr.blocks[p] = d
+            else:
+                raise TypeError(b)
+        pr.emb_w = torch.cat(ws, dim=0).contiguous()
+        pr.emb_b = torch.cat(bs, dim=0).contiguous()
+        pr.emb_total = off
+        pr.zero_bias = torch.zeros(max(zmax, 32), dtype=torch.float32, device=dev)  # the bias-free Linear layers
+        pr.head = dict(g=f32("out.0.weight"), b=f32("out.0.bias"), w=pack(P["out.2.weight"]), cb=f32("out.2.bias"))
+        self._packed = pr
+        return pr
+
+    # ------------------------------------------------------------------ blocks
+    def _resblock(self, pr, s: SDResBlockSpec, x0, x1, emb):
+        d = pr.blocks[s.prefix]
+        aff1 = ops.gn_affine(x0, d["g1"], d["b1"], x1)
+        h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True, want_stats=True)
+        off = pr.emb_off[s.prefix]
+        aff2 = ops.gn_affine(h, d["g2"], d["b2"], add=emb[:, off:off + s.cout])
+        if s.has_skip_conv:
+            res = ops.conv(x0, d["ws"], d["wsb"], s.cout, 1, x1=x1)
+        else:
+            assert x1 is None
+            res = x0
+        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True)
+
+    def _transformer(self, pr, s: SDTransformerSpec, x, ctx_map, n_ctx):
+        d = pr.blocks[s.prefix]
+        n, hh, ww, c = x.shape
+        t, heads, dp, inner = hh * ww, s.heads, d["dp"], s.inner
+        hd = heads * dp
+        scale = float(s.d_head) ** -0.5
+        zb = pr.zero_bias
+        aff = ops.gn_affine(x, d["g"], d["b"], eps=1e-6)
+        h = ops.conv(x, d["w_in"], d["b_in"], inner, 1, aff=aff, silu=False)
+        for L in d["layers"]:
+            # self-attention
+            y = ops.layernorm(h, *L["norm1"])
+            qkv = ops.conv(y, L["qkv1"], zb, 3 * hd, 1).view(n, t, 3 * hd)
+            a = ops.attention_cross(qkv, qkv[:, :, hd:], heads, dp, t, scale)
+            h = ops.conv(a.view(n, hh, ww, hd), L["o1"], L["o1b"], inner, 1, res=h)
+            # cross-attention over the conditioning tokens
+            y = ops.layernorm(h, *L["norm2"])
+            q = ops.conv(y, L["q2"], zb, hd, 1).view(n, t, hd)
+            kv = ops.conv(ctx_map, L["kv2"], zb, 2 * hd, 1)
+            a = ops.attention_cross(q, kv.view(n, -1, 2 * hd), heads, dp, n_ctx, scale)
+            h = ops.conv(a.view(n, hh, ww, hd), L["o2"], L["o2b"], inner, 1, res=h)
+            # gated feed-forward
+            y = ops.layernorm(h, *L["norm3"])
+            u = ops.conv(y, L["ff1"], L["ff1b"], 8 * inner, 1)
+            h = ops.conv(ops.geglu(u), L["ff2"], L["ff2b"], inner, 1, res=h)
+        return ops.conv(h, d["w_out"], d["b_out"], c, 1, res=x, want_stats=True)
+
+    def _run_seq(self, pr, seq, h, skip, emb, ctx_map, n_ctx, x_nchw=None):
+        first = True
+        for blk in seq:
+            d = pr.blocks[blk.prefix]
+            if isinstance(blk, SDStemSpec):
+                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32), d["w"], d["b"], blk.cout, 9, want_stats=True)
+            elif isinstance(blk, SDResBlockSpec):
+                h = self._resblock(pr, blk, h, skip if first else None, emb)
+            elif isinstance(blk, SDTransformerSpec):
+                h = self._transformer(pr, blk, h, ctx_map, n_ctx)
+            elif isinstance(blk, SDDownSpec):
+                h = ops.resample(ops.conv(h, d["w"], d["b"], blk.channels, 9), "stride2")
+            elif isinstance(blk, SDUpSpec):
+                h = ops.conv(h, d["w"], d["b"], blk.channels, 9, in_up=True, want_stats=True)
+            else:
+                raise TypeError(blk)
+            first = False
+        return h
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """x fp32 [N, C, H, W] latents, timesteps [N], context [N, S, context_dim] -> fp32 [N, out, H, W]."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        pr = self._packed or self._prepare()
+        plan: SDUNetPlan = self.plan
+        if not x.is_cuda:
+            raise AdmError("latent UNetModel.forward: x must be a device tensor (no CPU fallback)")
+        if context is None or context.dim() != 3 or context.shape[2] != plan.context_dim:
+            raise AdmError(f"context must be [N, S, {plan.context_dim}]")
+        n, s_ctx = x.shape[0], context.shape[1]
+        if s_ctx > 256:
+            raise NotImplementedError("more than 256 conditioning tokens")
+        x = x.to(torch.float32).contiguous()
+        with torch.no_grad():
+            # conditioning tokens as a bf16 pixel map (8x16 or 16x16, zero rows beyond S): the k|v projections are 1x1 convs
+            rows = 128 if s_ctx <= 128 else 256
+            ctx_map = torch.zeros((n, rows, plan.context_dim), dtype=torch.bfloat16, device=x.device)
+            ctx_map[:, :s_ctx] = context.to(device=x.device, dtype=torch.bfloat16)
+            ctx_map = ctx_map.view(n, rows // 16, 16, plan.context_dim)
+            e = ops.timestep_embedding(timesteps, plan.model_channels)
+            e = ops.linear_f32(e, pr.te0_w, pr.te0_b)
+            e = ops.linear_f32(e, pr.te2_w, pr.te2_b, silu_in=True)
+            emb = ops.linear_f32(e, pr.emb_w, pr.emb_b, silu_in=True)  # every ResBlock's emb_layers at once
+            hs: List[torch.Tensor] = []
+            h = None
+            for seq in plan.input_blocks:
+                h = self._run_seq(pr, seq, h, None, emb, ctx_map, s_ctx, x_nchw=x)
+                hs.append(h)
+            h = self._run_seq(pr, plan.middle_block, h, None, emb, ctx_map, s_ctx)
+            for seq in plan.output_blocks:
+                h = self._run_seq(pr, seq, h, hs.pop(), emb, ctx_map, s_ctx)
+            hd = pr.head
+            aff = ops.gn_affine(h, hd["g"], hd["b"])
+            return ops.conv(h, hd["w"], hd["cb"], plan.out_channels, 9, aff=aff, silu=True, out_f32_nchw=True)

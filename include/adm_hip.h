@@ -124,7 +124,8 @@ int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const float* par
 
 /* h_upd / x_upd of an up/down ResBlock (unet.py:190-195, 237-242):
  * out = resample(act(a*in + b)), act = SiLU when aff_a != NULL, identity copy otherwise.
- * mode 1 = AvgPool2d(2) (H,W -> H/2,W/2), mode 2 = nearest x2.                          */
+ * mode 1 = AvgPool2d(2) (H,W -> H/2,W/2), mode 2 = nearest x2, mode 3 = every second pixel
+ * (turns a stride-1 3x3 conv into the stride-2 Downsample of the latent UNet).             */
 int adm_resample(const adm_bf16* in, const float* aff_a, const float* aff_b, adm_bf16* out,
                  int n, int h, int w, int c, int mode, void* stream);
 
@@ -188,6 +189,29 @@ int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, i
  * P = exp2(s * log2(e)/sqrt(D) - lse).  Needed by adm_attention_bwd.                          */
 int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int t, int heads, int d,
                       int new_order, void* stream);
+
+/* Attention with separate query and key/value tensors, heads of any supported width laid out (h d), and an explicit
+ * logit scale: the SpatialTransformer's CrossAttention ("Stable Diffusion"/ldm/modules/attention.py:152-194:
+ * softmax(q k^T * dim_head^-0.5) v; self-attention when kv aliases the query tensor).
+ *   q   bf16 [N][tq][q_stride]       head h = columns h*d .. h*d+d
+ *   kv  bf16 [N][kv_rows][kv_stride] K head h = columns h*d .., V head h = columns heads*d + h*d ..; only the first
+ *                                    tk rows of every image are attended to (kv_rows >= tk is the row pitch)
+ *   out bf16 [N][tq][heads*d];  scale <= 0 selects 1/sqrt(d).  d in {32, 64, 128, 192, 256}: narrower reference heads
+ *   (40 / 80 / 160 channels) are zero-padded by the caller's projection weights, with scale = true_dim^-0.5.     */
+int adm_attention_cross(const adm_bf16* q, int q_stride, const adm_bf16* kv, int kv_stride, int kv_rows,
+                        adm_bf16* out, int n, int tq, int tk, int heads, int d, float scale, void* stream);
+
+/* ---------------------------------------------------------------- Stable-Diffusion latent UNet
+ * LayerNorm over the channels of every token (torch.nn.LayerNorm(C), attention.py:205-207): bf16 [rows][C] -> bf16.  */
+int adm_layernorm(const adm_bf16* x, const float* gamma, const float* beta, adm_bf16* out, int64_t rows, int c,
+                  float eps, void* stream);
+/* GEGLU gate (attention.py:36-44): out[r][i] = u[r][i] * gelu(u[r][inner+i]), u bf16 [rows][2*inner], exact GELU. */
+int adm_geglu(const adm_bf16* u, adm_bf16* out, int64_t rows, int inner, void* stream);
+/* GroupNorm affine of (x + e[n, c]) applied to the STORED x (ResBlock without scale-shift norm, openaimodel.py:253-258:
+ * h = h + emb_out; h = out_layers(h)): statistics of x + e are derived from the partial sums of x, and
+ * a = rstd*gamma, b = beta + (e - mean)*rstd*gamma.  add fp32 [N][add_stride].                                   */
+int adm_gn_finalize_add(const float* partial, const float* gamma, const float* beta, const float* add, int add_stride,
+                        float* aff_a, float* aff_b, int n, int c, int hw, int slabs, float eps, void* stream);
 
 /* ---------------------------------------------------------------- classifier guidance, backward-data (K10, A9)
  * The reference gets grad_x log p(y|x,t) from torch.autograd over EncoderUNetModel
