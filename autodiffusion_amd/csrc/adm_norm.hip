@@ -85,7 +85,8 @@ nchw_to_nhwc_pad_kernel(const float* __restrict__ x, uint16_t* __restrict__ out,
 // pixels, combined across pixel lanes through LDS, written as partial[n][slab][c][2].
 __global__ void __launch_bounds__(256)
 gn_partial_kernel(const uint16_t* __restrict__ in0, int c0, const uint16_t* __restrict__ in1, int c1,
-                  float* __restrict__ partial, int hw, int slabs) {
+                  float* __restrict__ partial, int hw, int slabs, int c_total, int c_off) {
+  // (c_total, c_off): this launch covers channels [c_off, c_off + c0 + c1) of rows that are c_total wide
   extern __shared__ __attribute__((aligned(16))) float red[];  // [lanes][c][2]
   const int c = c0 + c1;
   const int groups8 = c / 8;
@@ -120,7 +121,7 @@ gn_partial_kernel(const uint16_t* __restrict__ in0, int c0, const uint16_t* __re
   for (int i = threadIdx.x; i < c * 2; i += blockDim.x) {
     float t = 0.0f;
     for (int l = 0; l < lanes; ++l) t += red[(long long)l * c * 2 + i];
-    partial[(((long long)img * slabs + slab) * c) * 2 + i] = t;
+    partial[(((long long)img * slabs + slab) * c_total + c_off) * 2 + i] = t;
   }
 }
 
@@ -277,12 +278,21 @@ extern "C" int adm_gn_partial(const adm_bf16* in0, int c0, const adm_bf16* in1, 
   ADM_REQUIRE((in1 != nullptr) == (c1 > 0), ADM_E_ARG, "adm_gn_partial: in1/c1 mismatch");
   const int c = c0 + c1;
   ADM_REQUIRE(n > 0 && hw > 0 && slabs > 0 && slabs <= hw, ADM_E_ARG, "adm_gn_partial: bad n/hw/slabs");
-  ADM_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && c % 32 == 0 && c <= 2048, ADM_E_SHAPE,
+  ADM_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && c % 32 == 0 && c0 <= 2048 && c1 <= 2048, ADM_E_SHAPE,
               "adm_gn_partial: channels (%d + %d) unsupported", c0, c1);
   ADM_REQUIRE(adm_aligned16(in0) && adm_aligned16(in1), ADM_E_ALIGN, "adm_gn_partial: unaligned input");
-  const int lanes = 256 / (c / 8);
-  const size_t smem = (size_t)lanes * c * 2 * sizeof(float);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(slabs, n), dim3(256), smem, (hipStream_t)stream, in0, c0, in1, c1, partial, hw, slabs);
+  auto launch = [&](const adm_bf16* a, int ca, const adm_bf16* b, int cb, int c_off) {
+    const int cc = ca + cb;
+    const int lanes = 256 / (cc / 8);
+    const size_t smem = (size_t)lanes * cc * 2 * sizeof(float);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(slabs, n), dim3(256), smem, (hipStream_t)stream, a, ca, b, cb, partial, hw, slabs, c, c_off);
+  };
+  if (c <= 2048) {
+    launch(in0, c0, in1, c1, 0);
+  } else {  // a block covers at most 2048 channels: one launch per source of the concat (the SD UNet's 1280 | 1280)
+    launch(in0, c0, nullptr, 0, 0);
+    launch(in1, c1, nullptr, 0, c0);
+  }
   return adm_check_launch("adm_gn_partial");
 }
 

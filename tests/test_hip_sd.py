@@ -124,6 +124,10 @@ def test_sd_unet_matches_reference_golden(name):
     out = m(x, t, ctx)
     assert out.dtype == torch.float32 and out.shape == g["out"].shape
     check(out, g["out"], name)
+    m.enable_graph()  # hipGraph replay: bit-identical, and a second call with new inputs replays the same graph
+    assert torch.equal(m(x, t, ctx), out)
+    x2 = x.flip(0).contiguous() if x.shape[0] > 1 else x * 0.5
+    assert torch.equal(m(x2, t, ctx), m.enable_graph(False)(x2, t, ctx))
     if name == "sd_unet_tiny":  # ragged batch reproduces per-image results
         out3 = m(torch.cat([x, x[:1]]), torch.cat([t, t[:1]]), torch.cat([ctx, ctx[:1]]))
         assert torch.equal(out3[:2], out) and torch.equal(out3[2], out[0])

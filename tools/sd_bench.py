@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Time the full-size Stable-Diffusion v1 latent UNet (859.5 M parameters, 64x64 latents, 77 x 768 context) on the HIP
+path: ms per UNet evaluation, latents/s and model TFLOP/s (803.3 GFLOP per latent per evaluation).
+GRAPH=1 replays a captured hipGraph.  BATCH (default 12 = the reference's n_samples 6 with classifier-free guidance), REPS, BREAKDOWN=1 for per-shape conv time."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from autodiffusion_amd import ops  # noqa: E402
+from autodiffusion_amd.sd_arch import SD_V1  # noqa: E402
+from autodiffusion_amd.sd_unet import UNetModel  # noqa: E402
+
+DEV = "cuda:0"
+GFLOP_PER_LATENT = 803.27
+
+
+def main():
+    b = int(os.environ.get("BATCH", "12"))
+    reps = int(os.environ.get("REPS", "5"))
+    m = UNetModel(image_size=32, use_spatial_transformer=True, **SD_V1).to(DEV)
+    m.randomize_(1234)
+    if os.environ.get("GRAPH") == "1":
+        m.enable_graph()
+    x = torch.randn(b, 4, 64, 64, device=DEV)
+    t = torch.full((b,), 500, device=DEV, dtype=torch.int64)
+    ctx = torch.randn(b, 77, 768, device=DEV)
+    for _ in range(2):
+        out = m(x, t, ctx)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    if os.environ.get("BREAKDOWN") == "1":
+        ops.CONV_PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m(x, t, ctx)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"SD v1 UNet batch {b}: {dt * 1e3:.1f} ms / evaluation, {b / dt:.1f} latents/s, "
+          f"{b / dt * GFLOP_PER_LATENT / 1e3:.1f} model TFLOP/s")
+    if ops.CONV_PROFILE:
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        agg = {}
+        for e0, e1, f, key, shape in prof:
+            a = agg.setdefault((key, shape), [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1); a[1] += f; a[2] += 1
+        tot = sum(v[0] for v in agg.values()) / reps
+        print(f"conv launches: {tot:.1f} ms of {dt * 1e3:.1f} ms")
+        for (key, shape), (ms_, fl_, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+            print(f"  conv {key} nhwc_in={shape[:4]} cout={shape[4]} x{cnt // reps}: {ms_ / reps:8.2f} ms {fl_ / ms_ / 1e9:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
