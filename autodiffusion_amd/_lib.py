@@ -40,6 +40,12 @@ class ConvArgs(C.Structure):
     ]
 
 
+class SdStepCoefs(C.Structure):
+    """struct adm_sd_step_coefs (include/adm_hip.h)."""
+    _fields_ = [("cfg_scale", C.c_float), ("w", C.c_float * 4), ("sqrt_one_minus_at", C.c_float), ("sqrt_at", C.c_float),
+                ("sqrt_a_prev", C.c_float), ("dir_coef", C.c_float), ("sigma", C.c_float)]
+
+
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 
 # name -> (restype, argtypes); every symbol declared in include/adm_hip.h
@@ -81,6 +87,7 @@ SIGNATURES = {
     "adm_layernorm": (_I, [_P, _P, _P, _P, C.c_int64, _I, _F, _P]),
     "adm_geglu": (_I, [_P, _P, C.c_int64, _I, _P]),
     "adm_gn_finalize_add": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "adm_sd_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(SdStepCoefs), _P]),
     "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
 }
 

@@ -126,3 +126,51 @@ extern "C" int adm_geglu(const adm_bf16* u, adm_bf16* out, int64_t rows, int inn
   hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, u, out, (long long)rows, inner);
   return adm_check_launch("adm_geglu");
 }
+
+// ------------------------------------------------------------------------------------------------
+// One latent sampler update ("Stable Diffusion"/ldm/models/diffusion/ddim.py:165-203 p_sample_ddim,
+// plms.py:195-258 p_sample_plms): classifier-free guidance combine, multistep eps blend, pred_x0 and x_prev in one
+// pass over the latents (fp32, 5-7 streams instead of ~12 separate elementwise launches).
+namespace {
+struct SdStep {
+  const float* x; const float* eu; const float* ec; const float* h1; const float* h2; const float* h3; const float* noise;
+  float* x_prev; float* pred_x0; float* e_out;
+  long long numel;
+  float cfg, w0, w1, w2, w3, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma;
+};
+
+__global__ void __launch_bounds__(256)
+sd_step_kernel(const SdStep p) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.numel; i += (long long)gridDim.x * blockDim.x) {
+    float e = p.ec[i];
+    if (p.eu) {
+      const float u = p.eu[i];
+      e = u + p.cfg * (e - u);
+    }
+    if (p.e_out) p.e_out[i] = e;
+    float ep = p.w0 * e;
+    if (p.h1) ep += p.w1 * p.h1[i];
+    if (p.h2) ep += p.w2 * p.h2[i];
+    if (p.h3) ep += p.w3 * p.h3[i];
+    const float x0 = (p.x[i] - p.sqrt_one_minus_at * ep) / p.sqrt_at;
+    float xp = p.sqrt_a_prev * x0 + p.dir_coef * ep;
+    if (p.noise) xp += p.sigma * p.noise[i];
+    p.x_prev[i] = xp;
+    if (p.pred_x0) p.pred_x0[i] = x0;
+  }
+}
+}  // namespace
+
+extern "C" int adm_sd_step(const float* x, const float* eps_uncond, const float* eps_cond, const float* h1, const float* h2,
+                           const float* h3, const float* noise, float* x_prev, float* pred_x0, float* e_out, int64_t numel,
+                           const adm_sd_step_coefs* c, void* stream) {
+  ADM_REQUIRE(x && eps_cond && x_prev && c, ADM_E_ARG, "adm_sd_step: null pointer");
+  ADM_REQUIRE(numel > 0, ADM_E_ARG, "adm_sd_step: empty tensor");
+  ADM_REQUIRE(c->sqrt_at > 0.f, ADM_E_ARG, "adm_sd_step: sqrt(alpha_t) must be positive");
+  SdStep p{x, eps_uncond, eps_cond, h1, h2, h3, noise, x_prev, pred_x0, e_out, (long long)numel,
+           c->cfg_scale, c->w[0], c->w[1], c->w[2], c->w[3], c->sqrt_one_minus_at, c->sqrt_at, c->sqrt_a_prev, c->dir_coef, c->sigma};
+  long long blocks = (numel + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(sd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return adm_check_launch("adm_sd_step");
+}

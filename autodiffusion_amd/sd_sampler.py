@@ -1,0 +1,250 @@
+"""Latent-diffusion samplers with a searched timestep list on the HIP path.
+
+Host-side mirror of the reference's ``DDIMSampler`` / ``PLMSSampler`` ("Stable Diffusion"/ldm/models/diffusion/ddim.py:60-203,
+plms.py:63-258) as AutoDiffusion drives them (scripts/search_ea.py:528-538): ``sampler.sample(S, batch_size, shape,
+conditioning, ..., unconditional_guidance_scale, unconditional_conditioning, eta, x_T, sampled_timestep=cand)`` returning
+``(samples, intermediates)``, attribute ``ddpm_num_timesteps``.  ``model`` is anything with the attributes the reference
+samplers read from ``LatentDiffusion`` -- ``num_timesteps, betas, alphas_cumprod, alphas_cumprod_prev, device,
+apply_model(x, t, c)`` -- e.g. ``LatentDiffusion`` below around the HIP latent UNet (``sd_unet.UNetModel``).
+
+Every update (classifier-free-guidance combine, PLMS multistep blend, pred_x0, x_prev) is ONE ``adm_sd_step`` launch; the
+per-step scalars are computed on the host in float32 exactly as the reference's float32 tables hold them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdmError, SdStepCoefs, check
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """ldm/modules/diffusionmodules/util.py:21-43 (float64)."""
+    if schedule == "linear":
+        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    elif schedule == "cosine":
+        ts = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
+        al = np.cos(ts / (1 + cosine_s) * np.pi / 2) ** 2
+        al = al / al[0]
+        betas = np.clip(1 - al[1:] / al[:-1], 0, 0.999)
+    elif schedule == "sqrt_linear":
+        betas = np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
+    elif schedule == "sqrt":
+        betas = np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64) ** 0.5
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    """util.py:46-63 (the reference rounds the stride, it does not floor it)."""
+    if ddim_discr_method == "uniform":
+        c = round(num_ddpm_timesteps / num_ddim_timesteps)
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    return ddim_timesteps + 1
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """util.py:66-78 on float32 values: (sigmas, alphas, alphas_prev), numpy float32."""
+    ac = np.asarray(alphacums, dtype=np.float32)
+    steps = [int(t) for t in ddim_timesteps]
+    alphas = ac[steps]
+    alphas_prev = np.concatenate([ac[:1], ac[steps[:-1]]]).astype(np.float32)
+    one = np.float32(1.0)
+    sigmas = np.float32(eta) * np.sqrt((one - alphas_prev) / (one - alphas) * (one - alphas / alphas_prev))
+    return sigmas.astype(np.float32), alphas, alphas_prev
+
+
+class LatentDiffusion:
+    """The slice of ``ldm.models.diffusion.ddpm.LatentDiffusion`` the samplers use (register_schedule ddpm.py:117-137,
+    apply_model with ``conditioning_key: crossattn``): float32 schedule tables and the UNet call."""
+
+    parameterization = "eps"
+
+    def __init__(self, unet, timesteps=1000, beta_schedule="linear", linear_start=0.00085, linear_end=0.0120,
+                 cosine_s=8e-3, device=None):
+        betas = make_beta_schedule(beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end,
+                                   cosine_s=cosine_s)
+        ac = np.cumprod(1.0 - betas, axis=0)
+        self.num_timesteps = int(timesteps)
+        self.device = torch.device(device) if device is not None else getattr(unet, "device", torch.device("cpu"))
+        self.betas = torch.tensor(betas, dtype=torch.float32, device=self.device)
+        self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32, device=self.device)
+        self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32, device=self.device)
+        self.model = unet
+
+    def apply_model(self, x_noisy, t, cond):
+        return self.model(x_noisy, t, context=cond)
+
+
+def _f32ptr(t, name):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise AdmError(f"{name}: expected a contiguous float32 device tensor (the HIP path has no CPU fallback)")
+    return t.data_ptr()
+
+
+def sd_step(x, eps, batch, cfg_scale, weights, hist, a_t, a_prev, sigma, noise=None, want_e=True):
+    """One fused update.  eps: model output, [2*batch, ...] (unconditional half first) under guidance, else [batch, ...].
+    weights/hist: multistep blend e' = w[0]*e + sum w[k]*hist[k-1].  a_t, a_prev, sigma: float32 scalars.
+    Returns (x_prev, pred_x0, e)."""
+    guided = eps.shape[0] == 2 * batch
+    if not guided and eps.shape[0] != batch:
+        raise AdmError(f"sd_step: model output batch {eps.shape[0]} is neither {batch} nor {2 * batch}")
+    eps = eps.contiguous()
+    eu, ec = (eps[:batch], eps[batch:]) if guided else (None, eps)
+    x_prev, pred = torch.empty_like(x), torch.empty_like(x)
+    e_out = torch.empty_like(x) if want_e else None
+    one = np.float32(1.0)
+    a_t, a_prev, sigma = np.float32(a_t), np.float32(a_prev), np.float32(sigma)
+    co = SdStepCoefs()
+    co.cfg_scale = float(cfg_scale)
+    w = list(weights) + [0.0] * (4 - len(weights))
+    co.w = (C.c_float * 4)(*[float(v) for v in w])
+    co.sqrt_one_minus_at = float(np.sqrt(one - a_t))
+    co.sqrt_at = float(np.sqrt(a_t))
+    co.sqrt_a_prev = float(np.sqrt(a_prev))
+    co.dir_coef = float(np.sqrt(one - a_prev - sigma * sigma))
+    co.sigma = float(sigma)
+    h = list(hist) + [None] * (3 - len(hist))
+    check(_lib.load().adm_sd_step(_f32ptr(x, "x"), _f32ptr(eu, "eps"), _f32ptr(ec, "eps"), _f32ptr(h[0], "old_eps"),
+                                  _f32ptr(h[1], "old_eps"), _f32ptr(h[2], "old_eps"), _f32ptr(noise, "noise"),
+                                  x_prev.data_ptr(), pred.data_ptr(), None if e_out is None else e_out.data_ptr(),
+                                  x.numel(), C.byref(co), torch.cuda.current_stream().cuda_stream), "adm_sd_step")
+    return x_prev, pred, e_out
+
+
+class _LatentSampler:
+    def __init__(self, model, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True, sampled_timestep=None):
+        if sampled_timestep is None:
+            self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        else:
+            self.ddim_timesteps = sampled_timestep
+        ac = self.model.alphas_cumprod
+        assert ac.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
+        self.alphas_cumprod_host = ac.detach().to(torch.float32).cpu().numpy()
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = make_ddim_sampling_parameters(
+            self.alphas_cumprod_host, self.ddim_timesteps, ddim_eta, verbose)
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(np.float32(1.0) - self.ddim_alphas)
+
+    def _unsupported(self, **kw):
+        bad = [k for k, v in kw.items() if v]
+        if bad:
+            raise NotImplementedError(f"{type(self).__name__}: {bad} are not built on the HIP path (unused by search_ea.py)")
+
+    def _guided_input(self, x, t, c, uc, scale):
+        if uc is None or scale == 1.:
+            return x, t, c
+        return torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uc, c])
+
+    def _start(self, shape, x_T):
+        device = self.model.betas.device
+        if device.type != "cuda":
+            raise AdmError("latent samplers: the model's tables are on the CPU (the HIP path has no CPU fallback)")
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        return device, img.contiguous()
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
+               unconditional_conditioning=None, sampled_timestep=None, **kwargs):
+        self._unsupported(quantize_x0=quantize_x0, mask=mask is not None, noise_dropout=noise_dropout > 0.,
+                          score_corrector=score_corrector is not None)
+        if conditioning is not None and not isinstance(conditioning, dict) and conditioning.shape[0] != batch_size:
+            print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        sampled_timestep = self._order(sampled_timestep)
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose, sampled_timestep=sampled_timestep)
+        C_, H, W = shape
+        return self._loop(conditioning, (batch_size, C_, H, W), x_T=x_T, callback=callback, img_callback=img_callback,
+                          log_every_t=log_every_t, temperature=temperature,
+                          unconditional_guidance_scale=unconditional_guidance_scale,
+                          unconditional_conditioning=unconditional_conditioning)
+
+
+class DDIMSampler(_LatentSampler):
+    def _order(self, sampled_timestep):
+        return None if sampled_timestep is None else sorted(int(t) for t in sampled_timestep)  # ddim.py:93-94
+
+    def _loop(self, cond, shape, x_T, callback, img_callback, log_every_t, temperature, unconditional_guidance_scale,
+              unconditional_conditioning):
+        device, img = self._start(shape, x_T)
+        b = shape[0]
+        timesteps = np.asarray(self.ddim_timesteps)
+        total = timesteps.shape[0]
+        intermediates = {'x_inter': [img], 'pred_x0': [img]}
+        for i, step in enumerate(np.flip(timesteps)):
+            index = total - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            eps = self.model.apply_model(*self._guided_input(img, ts, cond, unconditional_conditioning,
+                                                             unconditional_guidance_scale))
+            sigma = self.ddim_sigmas[index]
+            noise = torch.randn(shape, device=device) * temperature if sigma != 0 else None  # ddim.py:198 noise_like
+            img, pred_x0, _ = sd_step(img, eps, b, unconditional_guidance_scale, (1.0,), (), self.ddim_alphas[index],
+                                      self.ddim_alphas_prev[index], sigma, noise, want_e=False)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                intermediates['x_inter'].append(img)
+                intermediates['pred_x0'].append(pred_x0)
+        return img, intermediates
+
+
+class PLMSSampler(_LatentSampler):
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True, sampled_timestep=None):
+        if ddim_eta != 0:
+            raise ValueError('ddim_eta must be 0 for PLMS')
+        super().make_schedule(ddim_num_steps, ddim_discretize, ddim_eta, verbose, sampled_timestep)
+
+    def _order(self, sampled_timestep):
+        return sampled_timestep  # plms.py takes the list as given; search_ea.py sorts its candidates (:480)
+
+    def _loop(self, cond, shape, x_T, callback, img_callback, log_every_t, temperature, unconditional_guidance_scale,
+              unconditional_conditioning):
+        device, img = self._start(shape, x_T)
+        b = shape[0]
+        timesteps = np.asarray(self.ddim_timesteps)
+        total = timesteps.shape[0]
+        time_range = np.flip(timesteps)
+        intermediates = {'x_inter': [img], 'pred_x0': [img]}
+        uc, scale = unconditional_conditioning, unconditional_guidance_scale
+        old_eps = []
+        for i, step in enumerate(time_range):
+            index = total - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), device=device, dtype=torch.long)
+            a_t, a_prev, sigma = self.ddim_alphas[index], self.ddim_alphas_prev[index], self.ddim_sigmas[index]
+            eps = self.model.apply_model(*self._guided_input(img, ts, cond, uc, scale))
+            if len(old_eps) == 0:    # pseudo improved Euler (2nd order): a second model call at the predicted point
+                x_mid, _, e_t = sd_step(img, eps, b, scale, (1.0,), (), a_t, a_prev, sigma)
+                eps2 = self.model.apply_model(*self._guided_input(x_mid, ts_next, cond, uc, scale))
+                img, pred_x0, _ = sd_step(img, eps2, b, scale, (0.5, 0.5), (e_t,), a_t, a_prev, sigma, want_e=False)
+            else:                    # Adams-Bashforth of order 2 / 3 / 4 over the kept eps history (newest first)
+                w = {1: (3 / 2, -1 / 2), 2: (23 / 12, -16 / 12, 5 / 12), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[len(old_eps)]
+                img, pred_x0, e_t = sd_step(img, eps, b, scale, w, tuple(reversed(old_eps)), a_t, a_prev, sigma)
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                intermediates['x_inter'].append(img)
+                intermediates['pred_x0'].append(pred_x0)
+        return img, intermediates

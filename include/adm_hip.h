@@ -213,6 +213,20 @@ int adm_geglu(const adm_bf16* u, adm_bf16* out, int64_t rows, int inner, void* s
 int adm_gn_finalize_add(const float* partial, const float* gamma, const float* beta, const float* add, int add_stride,
                         float* aff_a, float* aff_b, int n, int c, int hw, int slabs, float eps, void* stream);
 
+/* One DDIM / PLMS update of the latent samplers (ddim.py:165-203, plms.py:195-258), fp32 tensors of numel elements:
+ *   e     = eps_uncond ? eps_uncond + cfg_scale*(eps_cond - eps_uncond) : eps_cond        (written to e_out if given)
+ *   e'    = w[0]*e + w[1]*h1 + w[2]*h2 + w[3]*h3                        (h* nullable: PLMS's old_eps, newest first)
+ *   x0    = (x - sqrt_one_minus_at*e') / sqrt_at
+ *   x_prev = sqrt_a_prev*x0 + dir_coef*e' + sigma*noise                 (dir_coef = sqrt(1 - a_prev - sigma^2))  */
+typedef struct adm_sd_step_coefs {
+  float cfg_scale;
+  float w[4];
+  float sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma;
+} adm_sd_step_coefs;
+int adm_sd_step(const float* x, const float* eps_uncond, const float* eps_cond, const float* h1, const float* h2,
+                const float* h3, const float* noise, float* x_prev, float* pred_x0, float* e_out, int64_t numel,
+                const adm_sd_step_coefs* coefs_host, void* stream);
+
 /* ---------------------------------------------------------------- classifier guidance, backward-data (K10, A9)
  * The reference gets grad_x log p(y|x,t) from torch.autograd over EncoderUNetModel
  * (search_imagenet64_classifier_guidance.py:319-326, unet.py:685-896).  Here the backward network

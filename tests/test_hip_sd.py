@@ -146,3 +146,82 @@ def test_sd_constructor_mirrors_the_reference_and_rejects_unbuilt_variants():
     with pytest.raises(NotImplementedError):
         UNetModel(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[1],
                   num_heads=2, use_spatial_transformer=True, context_dim=96, use_scale_shift_norm=True)
+
+
+# ------------------------------------------------------------------ latent samplers
+class _ToyLatentModel:
+    """The attributes of LatentDiffusion the samplers read; apply_model = the capture script's toy model, on the GPU."""
+
+    def __init__(self):
+        from autodiffusion_amd.sd_sampler import LatentDiffusion
+        base = LatentDiffusion(None, device=DEV)
+        self.num_timesteps, self.device = base.num_timesteps, base.device
+        self.betas, self.alphas_cumprod, self.alphas_cumprod_prev = base.betas, base.alphas_cumprod, base.alphas_cumprod_prev
+        self.calls = 0
+
+    def apply_model(self, x, t, c):
+        from oracle.sd_sampler import toy_model
+        self.calls += 1
+        return toy_model(x, t, c)
+
+
+def test_latent_samplers_match_reference_goldens():
+    from autodiffusion_amd.sd_sampler import DDIMSampler, PLMSSampler
+    g = golden("sd_samplers")
+    x_T, c, uc = (torch.from_numpy(g[k]).to(DEV) for k in ("x_T", "c", "uc"))
+    m = _ToyLatentModel()
+    np.testing.assert_array_equal(m.alphas_cumprod.cpu().numpy(), g["alphas_cumprod"])
+    for tag in ("k4", "k6", "k1"):
+        cand = g[f"cand_{tag}"]
+        for name, cls in (("ddim", DDIMSampler), ("plms", PLMSSampler)):
+            for gtag, (scale, u) in {"cfg": (7.5, uc), "plain": (1.0, None)}.items():
+                st = np.array(sorted(cand)) if name == "plms" else cand
+                s = cls(m)
+                assert s.ddpm_num_timesteps == 1000
+                got, inter = s.sample(S=len(cand), batch_size=3, shape=[4, 8, 8], conditioning=c, verbose=False, eta=0.0,
+                                      x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=u,
+                                      sampled_timestep=st)
+                np.testing.assert_allclose(got.cpu().numpy(), g[f"{name}_{tag}_{gtag}"], rtol=2e-5, atol=2e-5,
+                                           err_msg=f"{name} {tag} {gtag}")
+                assert len(inter["x_inter"]) >= 2
+    got, _ = DDIMSampler(m).sample(S=4, batch_size=3, shape=[4, 8, 8], conditioning=c, verbose=False, x_T=x_T)
+    np.testing.assert_allclose(got.cpu().numpy(), g["ddim_uniform4_plain"], rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        PLMSSampler(m).sample(S=4, batch_size=3, shape=[4, 8, 8], conditioning=c, eta=0.5, x_T=x_T)
+    with pytest.raises(NotImplementedError):
+        DDIMSampler(m).sample(S=4, batch_size=3, shape=[4, 8, 8], conditioning=c, x_T=x_T, mask=torch.ones(1))
+
+
+def test_ddim_step_with_noise_matches_the_oracle_formula():
+    from autodiffusion_amd.sd_sampler import sd_step
+    from oracle import sd_sampler as S
+    g = torch.Generator().manual_seed(3)
+    x, eu, ec, noise = (torch.randn(2, 4, 16, 16, generator=g) for _ in range(4))
+    ac = S.alphas_cumprod_f32()
+    sig, a, a_prev = S.sampling_parameters(ac, [100, 400, 900], eta=0.7)
+    e = eu + 5.0 * (ec - eu)
+    want_xp, want_x0 = S._update(x, e, a[1], a_prev[1], sig[1], noise)
+    xp, x0, e_out = sd_step(x.to(DEV), torch.cat([eu, ec]).to(DEV), 2, 5.0, (1.0,), (), a[1].item(), a_prev[1].item(),
+                            sig[1].item(), noise.to(DEV))
+    np.testing.assert_allclose(e_out.cpu().numpy(), e.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(x0.cpu().numpy(), want_x0.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xp.cpu().numpy(), want_xp.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_sd_search_path_end_to_end_tiny_unet_against_the_oracle():
+    """sampler.sample(..., sampled_timestep=cand) over the HIP latent UNet with classifier-free guidance, against the
+    oracle sampler over the oracle UNet (both golden-pinned); bf16 torso tolerance as above."""
+    from autodiffusion_amd.sd_sampler import LatentDiffusion, PLMSSampler
+    from oracle import sd_nets, sd_sampler as S
+    g, plan, P = sd_case("sd_unet_tiny")
+    unet = _model(plan, P)
+    ld = LatentDiffusion(unet, device=DEV)
+    x_T, ctx = torch.from_numpy(g["x"]), torch.from_numpy(g["context"])
+    uc = ctx.flip(1).contiguous() * 0.5
+    cand = [153, 424, 690, 926]
+    got, _ = PLMSSampler(ld).sample(S=4, batch_size=2, shape=[4, 16, 16], conditioning=ctx.to(DEV), verbose=False,
+                                    x_T=x_T.to(DEV), unconditional_guidance_scale=3.0,
+                                    unconditional_conditioning=uc.to(DEV), sampled_timestep=np.array(cand))
+    ref = S.plms_sample(lambda x, t, c: sd_nets.sd_unet_forward(P, plan, x, t, c), S.alphas_cumprod_f32(), x_T, ctx, cand,
+                        uc=uc, scale=3.0)
+    check(got, ref.numpy(), "PLMS 4-step, tiny latent UNet, cfg 3.0", 3e-2, 8e-2)

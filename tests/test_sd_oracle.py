@@ -37,3 +37,23 @@ def test_sd_v1_plan_matches_the_published_architecture():
     assert shapes["input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight"] == (320, 768)
     assert shapes["output_blocks.2.1.conv.weight"] == (1280, 1280, 3, 3)
     assert shapes["output_blocks.5.2.conv.weight"] == (1280, 1280, 3, 3)
+
+
+# ------------------------------------------------------------------ latent samplers (DDIM / PLMS, searched timesteps)
+def test_sd_sampler_oracle_matches_reference_samplers():
+    from oracle import sd_sampler as S
+    g = golden("sd_samplers")
+    ac = S.alphas_cumprod_f32()
+    np.testing.assert_array_equal(ac.numpy(), g["alphas_cumprod"])
+    for n in (4, 10, 50):
+        np.testing.assert_array_equal(S.uniform_timesteps(n), g[f"uniform_{n}"])
+    x_T, c, uc = (torch.from_numpy(g[k]) for k in ("x_T", "c", "uc"))
+    for tag in ("k4", "k6", "k1"):
+        steps = sorted(g[f"cand_{tag}"].tolist())
+        for gtag, (scale, u) in {"cfg": (7.5, uc), "plain": (1.0, None)}.items():
+            got = S.ddim_sample(S.toy_model, ac, x_T, c, steps, uc=u, scale=scale)
+            np.testing.assert_allclose(got.numpy(), g[f"ddim_{tag}_{gtag}"], rtol=2e-5, atol=2e-5)
+            got = S.plms_sample(S.toy_model, ac, x_T, c, steps, uc=u, scale=scale)
+            np.testing.assert_allclose(got.numpy(), g[f"plms_{tag}_{gtag}"], rtol=2e-5, atol=2e-5)
+    got = S.ddim_sample(S.toy_model, ac, x_T, c, S.uniform_timesteps(4))
+    np.testing.assert_allclose(got.numpy(), g["ddim_uniform4_plain"], rtol=2e-5, atol=2e-5)
