@@ -88,6 +88,7 @@ SIGNATURES = {
     "adm_geglu": (_I, [_P, _P, C.c_int64, _I, _P]),
     "adm_gn_finalize_add": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
     "adm_sd_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(SdStepCoefs), _P]),
+    "adm_dpm_step": (_I, [_P, _P, _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _F, _P]),
     "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
 }
 

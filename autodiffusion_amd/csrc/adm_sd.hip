@@ -174,3 +174,45 @@ extern "C" int adm_sd_step(const float* x, const float* eps_uncond, const float*
   hipLaunchKernelGGL(sd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   return adm_check_launch("adm_sd_step");
 }
+
+// ------------------------------------------------------------------------------------------------
+// One multistep DPM-Solver++ update in data-prediction form (dpm_solver.py:755-810 second order, 700-735 first order;
+// model_wrapper's classifier-free guidance + data_prediction_fn :289-330, 380-400):
+//   e = eu ? eu + cfg*(ec - eu) : ec;   m = (x - sigma_s*e) / alpha_s          (kept: the next step's model_prev)
+//   x_next = a*x + b0*m + b1*m_prev
+namespace {
+struct DpmStep {
+  const float* x; const float* eu; const float* ec; const float* m_prev;
+  float* x_next; float* m_out;
+  long long numel;
+  float cfg, sigma_s, alpha_s, a, b0, b1;
+};
+__global__ void __launch_bounds__(256)
+dpm_step_kernel(const DpmStep p) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.numel; i += (long long)gridDim.x * blockDim.x) {
+    float e = p.ec[i];
+    if (p.eu) {
+      const float u = p.eu[i];
+      e = u + p.cfg * (e - u);
+    }
+    const float x = p.x[i];
+    const float m = (x - p.sigma_s * e) / p.alpha_s;
+    float xn = p.a * x + p.b0 * m;
+    if (p.m_prev) xn += p.b1 * p.m_prev[i];
+    p.x_next[i] = xn;
+    if (p.m_out) p.m_out[i] = m;
+  }
+}
+}  // namespace
+
+extern "C" int adm_dpm_step(const float* x, const float* eps_uncond, const float* eps_cond, const float* m_prev, float* x_next,
+                            float* m_out, int64_t numel, float cfg_scale, float sigma_s, float alpha_s, float a, float b0,
+                            float b1, void* stream) {
+  ADM_REQUIRE(x && eps_cond && x_next, ADM_E_ARG, "adm_dpm_step: null pointer");
+  ADM_REQUIRE(numel > 0 && alpha_s > 0.f, ADM_E_ARG, "adm_dpm_step: empty tensor or alpha_s <= 0");
+  DpmStep p{x, eps_uncond, eps_cond, m_prev, x_next, m_out, (long long)numel, cfg_scale, sigma_s, alpha_s, a, b0, b1};
+  long long blocks = (numel + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dpm_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return adm_check_launch("adm_dpm_step");
+}

@@ -248,3 +248,109 @@ class PLMSSampler(_LatentSampler):
                 intermediates['x_inter'].append(img)
                 intermediates['pred_x0'].append(pred_x0)
         return img, intermediates
+
+
+# ------------------------------------------------------------------ DPM-Solver++(2M)
+class NoiseScheduleVP:
+    """The 'discrete' VP schedule of dpm_solver.py:99-156: log(alpha_t) is the piecewise-linear interpolant of
+    0.5*log(alphas_cumprod) over t = 1/N .. 1 (linear extrapolation outside, as interpolate_fn :1144-1188)."""
+
+    def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None):
+        if schedule != "discrete":
+            raise NotImplementedError("only the discrete schedule is used by DPMSolverSampler (sampler.py:60)")
+        ac = np.asarray(torch.as_tensor(alphas_cumprod).detach().cpu(), dtype=np.float64) if alphas_cumprod is not None \
+            else np.cumprod(1.0 - np.asarray(torch.as_tensor(betas).detach().cpu(), dtype=np.float64))
+        self.schedule, self.total_N, self.T = schedule, len(ac), 1.0
+        self.log_alpha_array = 0.5 * np.log(ac)
+        self.t_array = np.linspace(0.0, 1.0, self.total_N + 1)[1:]
+
+    def marginal_log_mean_coeff(self, t: float) -> float:
+        k = min(max(int(np.searchsorted(self.t_array, t)), 1), self.total_N - 1)
+        x0, x1 = self.t_array[k - 1], self.t_array[k]
+        y0, y1 = self.log_alpha_array[k - 1], self.log_alpha_array[k]
+        return float(y0 + (t - x0) * (y1 - y0) / (x1 - x0))
+
+    def marginal_alpha(self, t):
+        return float(np.exp(self.marginal_log_mean_coeff(t)))
+
+    def marginal_std(self, t):
+        return float(np.sqrt(1.0 - np.exp(2.0 * self.marginal_log_mean_coeff(t))))
+
+    def marginal_lambda(self, t):
+        lm = self.marginal_log_mean_coeff(t)
+        return lm - 0.5 * float(np.log(1.0 - np.exp(2.0 * lm)))
+
+
+def dpm_step(x, eps, batch, cfg_scale, m_prev, sigma_s, alpha_s, a, b0, b1):
+    """One fused multistep update; returns (x_next, m) with m the data prediction at the current point."""
+    guided = eps.shape[0] == 2 * batch
+    if not guided and eps.shape[0] != batch:
+        raise AdmError(f"dpm_step: model output batch {eps.shape[0]} is neither {batch} nor {2 * batch}")
+    eps = eps.contiguous()
+    eu, ec = (eps[:batch], eps[batch:]) if guided else (None, eps)
+    x_next, m = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.load().adm_dpm_step(_f32ptr(x, "x"), _f32ptr(eu, "eps"), _f32ptr(ec, "eps"), _f32ptr(m_prev, "model_prev"),
+                                   x_next.data_ptr(), m.data_ptr(), x.numel(), float(cfg_scale), float(sigma_s),
+                                   float(alpha_s), float(a), float(b0), float(b1),
+                                   torch.cuda.current_stream().cuda_stream), "adm_dpm_step")
+    return x_next, m
+
+
+class DPMSolverSampler(_LatentSampler):
+    """dpm_solver/sampler.py:5-83: multistep DPM-Solver++ of order 2 in data-prediction form, ``lower_order_final``,
+    classifier-free guidance, over K+1 searched time points (``sampled_timestep``: integers index the ascending
+    1000-point uniform time grid in the given order; floats are continuous times, sorted descending --
+    dpm_solver.py:1079-1091) or the uniform grid when none are given."""
+
+    def __init__(self, model, **kwargs):
+        super().__init__(model, **kwargs)
+        self.alphas_cumprod = model.alphas_cumprod.detach().to(torch.float32)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
+               unconditional_conditioning=None, sampled_timestep=None, **kwargs):
+        if conditioning is not None and not isinstance(conditioning, dict) and conditioning.shape[0] != batch_size:
+            print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        C_, H, W = shape
+        device, x = self._start((batch_size, C_, H, W), x_T)
+        ns = NoiseScheduleVP('discrete', alphas_cumprod=self.alphas_cumprod)
+        steps, order = int(S), 2
+        assert steps >= order
+        if sampled_timestep is None:
+            ts = [float(v) for v in np.linspace(ns.T, 1.0 / ns.total_N, steps + 1, dtype=np.float32)]
+        else:
+            ea = [v.item() if hasattr(v, "item") else v for v in sampled_timestep]
+            if max(ea) > 1:
+                full = np.linspace(ns.T, 1.0 / ns.total_N, 1000 + 1, dtype=np.float32)[::-1]
+                ts = [float(full[int(e)]) for e in ea]
+            else:
+                ts = [float(np.float32(t)) for t in sorted(ea, reverse=True)]
+        assert len(ts) - 1 == steps
+        uc, scale = unconditional_conditioning, unconditional_guidance_scale
+
+        def eps_at(x_, t):  # model_wrapper: discrete-time input (t - 1/N) * 1000, guidance batch = [uncond | cond]
+            t_in = torch.full((batch_size,), (t - 1.0 / ns.total_N) * 1000.0, device=device, dtype=torch.float32)
+            return self.model.apply_model(*self._guided_input(x_, t_in, conditioning, uc, scale))
+
+        m_prev, lam_prev = None, None
+        for step in range(1, steps + 1):
+            s, t = ts[step - 1], ts[step]
+            if step == 1:
+                step_order = 1
+            else:
+                step_order = min(order, steps + 1 - step) if steps < 15 else order  # lower_order_final
+            lam_s, lam_t = ns.marginal_lambda(s), ns.marginal_lambda(t)
+            h = lam_t - lam_s
+            phi = ns.marginal_alpha(t) * (np.exp(-h) - 1.0)
+            a = ns.marginal_std(t) / ns.marginal_std(s)
+            if step_order == 2:
+                r0 = (lam_s - lam_prev) / h
+                b0, b1 = -phi * (1.0 + 0.5 / r0), 0.5 * phi / r0
+            else:
+                b0, b1 = -phi, 0.0
+            x, m = dpm_step(x, eps_at(x, s), batch_size, scale, m_prev if step_order == 2 else None,
+                            ns.marginal_std(s), ns.marginal_alpha(s), a, b0, b1)
+            m_prev, lam_prev = m, lam_s
+        return x, None

@@ -227,6 +227,13 @@ int adm_sd_step(const float* x, const float* eps_uncond, const float* eps_cond, 
                 const float* h3, const float* noise, float* x_prev, float* pred_x0, float* e_out, int64_t numel,
                 const adm_sd_step_coefs* coefs_host, void* stream);
 
+/* One multistep DPM-Solver++ update in data-prediction form (dpm_solver/dpm_solver.py:700-735, 755-810 with
+ * model_wrapper's classifier-free guidance :289-330): e = guided eps, m = (x - sigma_s*e)/alpha_s (written to m_out, the
+ * next step's model_prev), x_next = a*x + b0*m + b1*m_prev (m_prev nullable: first-order step).  fp32, numel elements. */
+int adm_dpm_step(const float* x, const float* eps_uncond, const float* eps_cond, const float* m_prev, float* x_next,
+                 float* m_out, int64_t numel, float cfg_scale, float sigma_s, float alpha_s, float a, float b0, float b1,
+                 void* stream);
+
 /* ---------------------------------------------------------------- classifier guidance, backward-data (K10, A9)
  * The reference gets grad_x log p(y|x,t) from torch.autograd over EncoderUNetModel
  * (search_imagenet64_classifier_guidance.py:319-326, unet.py:685-896).  Here the backward network

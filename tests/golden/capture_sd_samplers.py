@@ -6,7 +6,8 @@ ddim.py, plms.py) driven with searched timestep lists (``sampled_timestep``), cl
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/capture_sd_samplers.py
 
 The reference's ``register_buffer`` moves every table to "cuda" (ddim.py:17-21); there is no GPU in this container,
-so the capture subclasses override it with a plain ``setattr`` (device placement only, no arithmetic).
+so the capture subclasses override it with a plain ``setattr`` (device placement only, no arithmetic); likewise the
+one ``torch.Tensor(timesteps).to('cuda')`` in dpm_solver.py:1088/1091 is routed to the CPU for the DPM-Solver runs.
 """
 import os
 import sys
@@ -22,6 +23,8 @@ sys.path.insert(0, ROOT)
 
 from ldm.models.diffusion.ddim import DDIMSampler  # noqa: E402
 from ldm.models.diffusion.plms import PLMSSampler  # noqa: E402
+from ldm.models.diffusion.dpm_solver import dpm_solver as _dpm  # noqa: E402
+from ldm.models.diffusion.dpm_solver.sampler import DPMSolverSampler  # noqa: E402
 from ldm.modules.diffusionmodules.util import make_beta_schedule  # noqa: E402
 from oracle.sd_sampler import toy_model  # noqa: E402
 
@@ -50,6 +53,22 @@ class CpuPLMS(PLMSSampler):
         setattr(self, name, attr)
 
 
+class CpuDPM(DPMSolverSampler):
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+
+# dpm_solver.py:1088/1091 builds its time points with ``torch.Tensor(list).to('cuda')``; no GPU here, so the capture
+# routes that one call to the CPU (device placement only)
+def _tensor_on_cpu(data):
+    t = torch.tensor(data, dtype=torch.float32)
+
+    class _T:
+        def to(self, *_a, **_k):
+            return t
+    return _T()
+
+
 if __name__ == "__main__":
     g = torch.Generator().manual_seed(7)
     b, shape = 3, (4, 8, 8)
@@ -68,6 +87,25 @@ if __name__ == "__main__":
                                      x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=ucond,
                                      sampled_timestep=st)
                 out[f"{name}_{tag}_{gtag}"] = s.numpy()
+    # DPM-Solver++(2M): integer candidates (indices into the 1000-point time grid) and continuous-time candidates
+    class _TorchShim:
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def Tensor(data):
+            return _tensor_on_cpu(data)
+    _dpm.torch = _TorchShim()
+    dpm_cands = {"i4": [999, 750, 500, 250, 0], "i6": [980, 901, 640, 433, 210, 77, 3],
+                 "f4": [1.0, 0.7502, 0.5005, 0.2508, 0.001], "i2": [900, 450, 10]}
+    for tag, cand in dpm_cands.items():
+        out[f"dpmcand_{tag}"] = np.array(cand, dtype=np.float64)
+        for gtag, (scale, ucond) in {"cfg": (7.5, uc), "plain": (1.0, None)}.items():
+            s, _ = CpuDPM(m).sample(S=len(cand) - 1, batch_size=b, shape=list(shape), conditioning=c, verbose=False,
+                                    x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=ucond,
+                                    sampled_timestep=cand)
+            out[f"dpm_{tag}_{gtag}"] = s.numpy()
+    _dpm.torch = torch
     # the uniform schedule the samplers fall back to without a searched list
     for S in (4, 10, 50):
         d = CpuDDIM(m)

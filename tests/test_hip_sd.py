@@ -225,3 +225,26 @@ def test_sd_search_path_end_to_end_tiny_unet_against_the_oracle():
     ref = S.plms_sample(lambda x, t, c: sd_nets.sd_unet_forward(P, plan, x, t, c), S.alphas_cumprod_f32(), x_T, ctx, cand,
                         uc=uc, scale=3.0)
     check(got, ref.numpy(), "PLMS 4-step, tiny latent UNet, cfg 3.0", 3e-2, 8e-2)
+
+
+def test_dpm_solver_sampler_matches_reference_goldens():
+    from autodiffusion_amd.sd_sampler import DPMSolverSampler
+    g = golden("sd_samplers")
+    x_T, c, uc = (torch.from_numpy(g[k]).to(DEV) for k in ("x_T", "c", "uc"))
+    m = _ToyLatentModel()
+    for tag in ("i4", "i6", "f4", "i2"):
+        cand = g[f"dpmcand_{tag}"].tolist()
+        cand = [int(v) for v in cand] if max(cand) > 1 else cand
+        for gtag, (scale, u) in {"cfg": (7.5, uc), "plain": (1.0, None)}.items():
+            m.calls = 0
+            got, _ = DPMSolverSampler(m).sample(S=len(cand) - 1, batch_size=3, shape=[4, 8, 8], conditioning=c, verbose=False,
+                                                x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=u,
+                                                sampled_timestep=cand)
+            assert m.calls == len(cand) - 1  # the final model value is never evaluated (dpm_solver.py:1116-1118)
+            np.testing.assert_allclose(got.cpu().numpy(), g[f"dpm_{tag}_{gtag}"], rtol=1e-4, atol=1e-4, err_msg=f"{tag} {gtag}")
+    # without a searched list: the uniform time grid, against the oracle
+    from oracle import sd_sampler as S
+    got, _ = DPMSolverSampler(m).sample(S=5, batch_size=3, shape=[4, 8, 8], conditioning=c, verbose=False, x_T=x_T)
+    tp = [float(v) for v in np.linspace(1.0, 0.001, 6, dtype=np.float32)]
+    ref = S.dpm_sample(S.toy_model, S.alphas_cumprod_f32(), x_T.cpu(), c.cpu(), tp)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)

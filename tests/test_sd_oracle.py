@@ -57,3 +57,17 @@ def test_sd_sampler_oracle_matches_reference_samplers():
             np.testing.assert_allclose(got.numpy(), g[f"plms_{tag}_{gtag}"], rtol=2e-5, atol=2e-5)
     got = S.ddim_sample(S.toy_model, ac, x_T, c, S.uniform_timesteps(4))
     np.testing.assert_allclose(got.numpy(), g["ddim_uniform4_plain"], rtol=2e-5, atol=2e-5)
+
+
+def test_dpm_solver_oracle_matches_reference_sampler():
+    from oracle import sd_sampler as S
+    g = golden("sd_samplers")
+    ac = S.alphas_cumprod_f32()
+    x_T, c, uc = (torch.from_numpy(g[k]) for k in ("x_T", "c", "uc"))
+    assert S.dpm_time_points([999, 0])[0] == pytest.approx(0.999001, abs=1e-6) and S.dpm_time_points([999, 0])[1] == pytest.approx(0.001)
+    for tag in ("i4", "i6", "f4", "i2"):
+        cand = g[f"dpmcand_{tag}"].tolist()
+        tp = S.dpm_time_points([int(v) for v in cand] if max(cand) > 1 else cand)
+        for gtag, (scale, u) in {"cfg": (7.5, uc), "plain": (1.0, None)}.items():
+            got = S.dpm_sample(S.toy_model, ac, x_T, c, tp, uc=u, scale=scale)
+            np.testing.assert_allclose(got.numpy(), g[f"dpm_{tag}_{gtag}"], rtol=1e-4, atol=1e-4, err_msg=f"{tag} {gtag}")
