@@ -248,3 +248,20 @@ def test_dpm_solver_sampler_matches_reference_goldens():
     tp = [float(v) for v in np.linspace(1.0, 0.001, 6, dtype=np.float32)]
     ref = S.dpm_sample(S.toy_model, S.alphas_cumprod_f32(), x_T.cpu(), c.cpu(), tp)
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("ADM_SLOW_TESTS"), reason="full-size SD v1 UNet vs the CPU oracle: ~2 min of CPU (ADM_SLOW_TESTS=1)")
+def test_full_size_sd_v1_unet_matches_the_oracle():
+    """The real topology (859.5 M parameters: 320/640/1280 channels, heads of 40/80/160 channels, three Downsample /
+    Upsample pairs, 1280|1280 concat GroupNorms, 77 x 768 context) on one 64x64 latent, fill-rule weights."""
+    from autodiffusion_amd.sd_arch import SD_V1, sd_unet_plan
+    from oracle import sd_nets
+    from oracle.fill import fill_state_dict
+    plan = sd_unet_plan(**SD_V1)
+    P = {k: torch.from_numpy(v) for k, v in fill_state_dict(plan.param_shapes()).items()}
+    g = torch.Generator().manual_seed(21)
+    x, ctx = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 768, generator=g)
+    t = torch.tensor([637])
+    ref = sd_nets.sd_unet_forward(P, plan, x, t, ctx)
+    out = _model(plan, P)(x.to(DEV), t.to(DEV), ctx.to(DEV))
+    check(out, ref.numpy(), "SD v1 UNet, full size")
