@@ -71,13 +71,91 @@ def cpu_baseline(sample_batch=4):
                       f"{sample_batch} images = {4 * sample_batch} UNet evals, {dt:.1f} s"}
 
 
+SD_CAND = [94, 217, 354, 574, 834, 944]     # GD/sample_imagenet64_classifier_guidance_subnet.sh:11's 6-step candidate, sorted
+SD_GFLOP_LATENT = 803.27                    # per latent per UNet evaluation
+
+
+def run_sd(args, rank, world, dev, red_dev):
+    """BASELINE config 4: one step = one candidate-evaluation batch of the Stable-Diffusion example -- N latents
+    [N, 4, 64, 64] sampled with K = 6 searched DDIM steps under classifier-free guidance 7.5 (2 UNet evaluations per
+    step, batched as 2N latents) through the v1 latent UNet; random-init weights, synthetic 77 x 768 conditioning.
+    The VAE decode / CLIP encoder / pytorch_fid ends of the reference's get_cand_fid are not on this path."""
+    import torch.distributed as dist
+    from autodiffusion_amd import ops
+    from autodiffusion_amd.sd_arch import SD_V1
+    from autodiffusion_amd.sd_sampler import DDIMSampler, LatentDiffusion
+    from autodiffusion_amd.sd_unet import UNetModel
+    n = args.batch or 6
+    unet = UNetModel(image_size=32, use_spatial_transformer=True, **SD_V1).to(dev)
+    unet.randomize_(1234).enable_graph()
+    sampler = DDIMSampler(LatentDiffusion(unet, device=dev))
+    g = torch.Generator(device=dev).manual_seed(99)
+    c, uc = (torch.randn(n, 77, 768, device=dev, generator=g) for _ in range(2))
+
+    def one_step(idx):
+        x_T = torch.randn(n, 4, 64, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(1000003 * idx + rank + 7))
+        return sampler.sample(S=len(SD_CAND), batch_size=n, shape=[4, 64, 64], conditioning=c, verbose=False, eta=0.0, x_T=x_T,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc, sampled_timestep=SD_CAND)[0]
+    for w in range(max(1, args.warmup)):
+        out = one_step(-1 - w)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in range(args.steps):
+        one_step(s_)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    roof = None
+    if not args.no_kernel_events:  # per-launch HIP events need the eager path: one untimed evaluation outside the graph
+        unet.enable_graph(False)
+        ops.CONV_PROFILE = []
+        x = torch.randn(2 * n, 4, 64, 64, device=dev)
+        unet(x, torch.full((2 * n,), 500, device=dev, dtype=torch.int64), torch.cat([uc, c]))
+        torch.cuda.synchronize()
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        dom = [p for p in prof if p[3] == (6, 9, True, 2)]
+        if dom:
+            ms = sum(p[0].elapsed_time(p[1]) for p in dom)
+            fl = sum(p[2] for p in dom)
+            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)",
+                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": len(dom),
+                    "avg_launch_us": round(ms * 1e3 / len(dom), 2), "avg_launch_gflop": round(fl / len(dom) / 1e9, 3)}
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        print(json.dumps({
+            "metric": "latents/sec (node), Stable-Diffusion v1 latent UNet, 6-step searched DDIM, guidance 7.5",
+            "value": round(value, 2), "unit": "latents/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (x_T ~ N(0,1), conditioning ~ N(0,1) [N,77,768], random-init weights of the SD v1 UNet architecture)",
+            "config": {"workload": f"Stable-Diffusion v1 latent UNet (859.5 M), searched DDIM {SD_CAND}, classifier-free guidance 7.5, "
+                                   f"{n} latents per GPU and step (64x64x4), bf16, hipGraph replay; VAE / CLIP / FID not on this path",
+                       "global_batch": world * n, "latent_size": 64, "sampler_steps": len(SD_CAND),
+                       "parallelism": f"dp{world} (latent-sharded, no data-path collective)"},
+            "model_tflops": round(value * 2 * len(SD_CAND) * SD_GFLOP_LATENT / 1e3, 1),
+            "roofline": roof}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--workload", default="auto", choices=["auto", "guided", "unguided"])
+    ap.add_argument("--batch", type=int, default=None, help="images per step and GPU (default 256; --workload sd: 6 latents)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "guided", "unguided", "sd"],
+                    help="auto/guided = the headline (ADM-G ImageNet-64, BASELINE configs[1]); sd = BASELINE config 4 "
+                         "(Stable-Diffusion v1 latent UNet, 6 searched DDIM steps, classifier-free guidance 7.5)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse N ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,6 +180,14 @@ def main():
         else:
             dist.init_process_group(backend="gloo", init_method="env://")
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+
+    if args.workload == "sd":
+        run_sd(args, rank, world, dev, red_dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.batch is None:
+        args.batch = 256
 
     from autodiffusion_amd import ops
     from autodiffusion_amd.evaluate import CandidateEvaluator

@@ -71,3 +71,69 @@ def test_dpm_solver_oracle_matches_reference_sampler():
         for gtag, (scale, u) in {"cfg": (7.5, uc), "plain": (1.0, None)}.items():
             got = S.dpm_sample(S.toy_model, ac, x_T, c, tp, uc=u, scale=scale)
             np.testing.assert_allclose(got.numpy(), g[f"dpm_{tag}_{gtag}"], rtol=1e-4, atol=1e-4, err_msg=f"{tag} {gtag}")
+
+
+# ------------------------------------------------------------------ product host logic (no GPU, no compute calls)
+def test_sd_sampler_host_tables_match_reference_goldens_and_oracle():
+    from autodiffusion_amd import sd_sampler as P
+    from oracle import sd_sampler as S
+    g = golden("sd_samplers")
+    ld = P.LatentDiffusion(None, device="cpu")
+    np.testing.assert_array_equal(ld.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    np.testing.assert_array_equal(ld.betas.numpy(), g["betas"])
+    assert ld.num_timesteps == 1000 and float(ld.alphas_cumprod_prev[0]) == 1.0
+    for n in (4, 10, 50):
+        np.testing.assert_array_equal(P.make_ddim_timesteps("uniform", n, 1000, verbose=False), g[f"uniform_{n}"])
+    with pytest.raises(NotImplementedError):
+        P.make_ddim_timesteps("log", 4, 1000)
+    ac = S.alphas_cumprod_f32()
+    for steps, eta in (([94, 217, 354, 574, 834, 944], 0.0), ([153, 424, 690, 926], 0.7), ([500], 0.3)):
+        sig, a, ap = P.make_ddim_sampling_parameters(ac.numpy(), steps, eta)
+        osig, oa, oap = S.sampling_parameters(ac, steps, eta)
+        np.testing.assert_array_equal(a, oa.numpy())
+        np.testing.assert_array_equal(ap, oap.numpy())
+        np.testing.assert_allclose(sig, osig.numpy(), rtol=1e-6, atol=0)
+    ns, ons = P.NoiseScheduleVP("discrete", alphas_cumprod=ac), S.DiscreteVP(ac)
+    for t in (1.0, 0.7502, 0.5, 0.001, 0.0005, 0.00125):
+        assert ns.marginal_log_mean_coeff(t) == pytest.approx(ons.log_mean(t), rel=1e-12)
+        assert ns.marginal_lambda(t) == pytest.approx(ons.lam(t), rel=1e-12)
+        assert ns.marginal_alpha(t) ** 2 + ns.marginal_std(t) ** 2 == pytest.approx(1.0, rel=1e-12)
+    # knots reproduce the discrete schedule exactly: t_k = (k+1)/1000 <-> alphas_cumprod[k]
+    assert ns.marginal_alpha(0.5) ** 2 == pytest.approx(float(ac[499]), rel=1e-6)
+    with pytest.raises(ValueError):
+        P.PLMSSampler(ld).make_schedule(4, ddim_eta=0.5)
+    with pytest.raises(ValueError):
+        P.make_beta_schedule("nope", 10)
+
+
+def test_sd_samplers_fail_loudly_without_a_gpu():
+    """No CPU fallback: with the tables on the CPU the samplers raise instead of computing."""
+    from autodiffusion_amd import sd_sampler as P
+    from autodiffusion_amd._lib import AdmError
+    ld = P.LatentDiffusion(None, device="cpu")
+    ld.apply_model = lambda x, t, c: x
+    for cls in (P.DDIMSampler, P.PLMSSampler, P.DPMSolverSampler):
+        with pytest.raises(AdmError):
+            cls(ld).sample(S=4, batch_size=1, shape=[4, 8, 8], conditioning=torch.zeros(1, 2, 8), verbose=False,
+                           x_T=torch.zeros(1, 4, 8, 8))
+
+
+def test_sd_unet_head_padding_is_exact():
+    """Zero-padding the 40-channel heads to 64 inside the projection weights leaves q.k and the output unchanged."""
+    from autodiffusion_amd.sd_unet import _pad_heads_in, _pad_heads_out, _padded_head
+    assert [_padded_head(d) for d in (32, 40, 64, 80, 160, 256)] == [32, 64, 64, 128, 192, 256]
+    g = torch.Generator().manual_seed(0)
+    heads, d, dp, cin, t = 8, 40, 64, 320, 5
+    wq, wk, wv = (torch.randn(heads * d, cin, generator=g) * cin ** -0.5 for _ in range(3))
+    wo = torch.randn(cin, heads * d, generator=g) * cin ** -0.5
+    x = torch.randn(t, cin, generator=g)
+
+    def attn(wq, wk, wv, wo, dd):
+        q, k, v = (x @ w.T for w in (wq, wk, wv))
+        q, k, v = (z.reshape(t, heads, dd).permute(1, 0, 2) for z in (q, k, v))
+        o = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, dim=-1) @ v
+        return o.permute(1, 0, 2).reshape(t, heads * dd) @ wo.T
+    ref = attn(wq, wk, wv, wo, d)
+    got = attn(_pad_heads_out(wq, heads, d, dp), _pad_heads_out(wk, heads, d, dp), _pad_heads_out(wv, heads, d, dp),
+               _pad_heads_in(wo, heads, d, dp), dp)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
