@@ -147,11 +147,14 @@ class EvolutionSearcher(object):
         t1 = time.time()
         if acc is not None:
             grp = None
-            if world == 1 and self.population_parallel:
-                st = FIDStatistics(*_local_stats(acc))
+            if getattr(args, "fid_on_device", False) and not (world == 1 and self.population_parallel):
+                fid = acc.frechet_distance_device(self.ref_stats, grp)  # eigh on the GPU instead of the host sqrtm
             else:
-                st = acc.statistics(grp)
-            fid = float(st.frechet_distance(self.ref_stats))
+                if world == 1 and self.population_parallel:
+                    st = FIDStatistics(*_local_stats(acc))
+                else:
+                    st = acc.statistics(grp)
+                fid = float(st.frechet_distance(self.ref_stats))
         else:
             if world > 1:
                 raise NotImplementedError("host-evaluator FID with several ranks: pass a device `features` function "

@@ -8,7 +8,8 @@ import pytest
 import torch
 from scipy import linalg
 
-from autodiffusion_amd.fid import ActivationAccumulator, FIDStatistics, compute_statistics
+from autodiffusion_amd.fid import (ActivationAccumulator, FIDStatistics, compute_statistics,
+                                   frechet_distance_device)
 from oracle import fid as ofid
 
 
@@ -48,6 +49,26 @@ def test_frechet_distance_rank_deficient_product():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert abs(ofid.frechet_distance(np.zeros(d), v, np.zeros(d), np.eye(d)) - got) < 1e-9
+
+
+def test_frechet_distance_symmetric_eigen_form_matches_the_host_formula():
+    """frechet_distance_device (float64 eigh; runs on whatever device holds the tensors -- here the CPU) against the
+    reference's sqrtm formula: well-conditioned, sample covariances, and rank-deficient (fewer samples than dimensions)."""
+    import warnings
+    rng = np.random.default_rng(5)
+    d = 48
+    cases = [(_spd(d, 1), _spd(d, 2))]
+    for n in (400, 30):  # 30 < d: singular covariance, as num_samples=1000 against 2048 Inception dimensions
+        a = rng.standard_normal((n, d)) @ rng.standard_normal((d, d)) * 0.3
+        b = rng.standard_normal((500, d)) @ rng.standard_normal((d, d)) * 0.3 + 0.1
+        cases.append((np.cov(a, rowvar=False), np.cov(b, rowvar=False)))
+    mu1, mu2 = rng.standard_normal(d), rng.standard_normal(d)
+    for s1, s2 in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = FIDStatistics(mu1, s1).frechet_distance(FIDStatistics(mu2, s2))
+        got = frechet_distance_device(*(torch.from_numpy(x) for x in (mu1, s1, mu2, s2)))
+        assert abs(got - want) <= 1e-7 * abs(want), (got, want)
 
 
 def test_compute_statistics_matches_oracle():
@@ -109,3 +130,33 @@ def test_gpu_accumulation_matches_numpy_float64():
     a64 = acts.numpy().astype(np.float64)
     np.testing.assert_allclose(st.mu, a64.mean(0), rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(st.sigma, np.cov(a64, rowvar=False), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.gpu
+def test_gpu_frechet_distance_matches_host_sqrtm_at_inception_width():
+    """2048 dimensions, 700 generated samples (rank-deficient covariance, the search's regime) against a full-rank
+    reference: the device eigen form vs the reference's host sqrtm formula; prints both wall times."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import warnings
+    d = 2048
+    g = torch.Generator().manual_seed(1)
+    mix = torch.randn(d, d, generator=g) * d ** -0.5
+    acts = (torch.randn(700, d, generator=g) @ mix) * 0.7 + 0.2
+    ref_acts = ((torch.randn(4096, d, generator=g) @ mix) * 0.8 + 0.25).numpy().astype(np.float64)
+    ref = FIDStatistics(ref_acts.mean(0), np.cov(ref_acts, rowvar=False))
+    acc = ActivationAccumulator(d, "cuda:0")
+    acc.add(acts.to("cuda:0"))
+    acc.frechet_distance_device(ref)  # first call loads the solver
+    torch.cuda.synchronize()
+    t0 = time.time()
+    got = acc.frechet_distance_device(ref)
+    t_dev = time.time() - t0
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = float(acc.statistics().frechet_distance(ref))
+    t_host = time.time() - t0
+    print(f"FID {got:.6f} (device, {t_dev:.2f} s) vs {want:.6f} (host sqrtm, {t_host:.2f} s)")
+    assert abs(got - want) <= 1e-6 * abs(want)
