@@ -1,5 +1,7 @@
 """Pin the Stable-Diffusion latent-UNet oracle against golden vectors captured from the reference's own modules
 (tests/golden/capture_sd.py -> sd_unet_*.npz)."""
+import ast
+
 import numpy as np
 import pytest
 import torch
@@ -13,7 +15,7 @@ from helpers import golden
 
 def sd_case(name):
     g = golden(name)
-    cfg = eval(str(g["cfg"]), {"__builtins__": {}})  # a dict literal written by capture_sd.py
+    cfg = ast.literal_eval(str(g["cfg"]))  # a dict literal written by capture_sd.py
     plan = sd_unet_plan(**cfg)
     P = {k: torch.from_numpy(v) for k, v in fill_state_dict(plan.param_shapes()).items()}
     return g, plan, P
