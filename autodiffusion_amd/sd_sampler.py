@@ -13,12 +13,16 @@ per-step scalars are computed on the host in float32 exactly as the reference's 
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 
 import numpy as np
 import torch
 
 from . import _lib
 from ._lib import AdmError, SdStepCoefs, check
+
+
+_CALL_IDS = itertools.count()  # one id per sample() call in this process: the context key handed to the model
 
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
@@ -80,8 +84,12 @@ class LatentDiffusion:
         self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32, device=self.device)
         self.model = unet
 
-    def apply_model(self, x_noisy, t, cond):
+    def apply_model(self, x_noisy, t, cond, context_key=None):
+        if context_key is not None and getattr(self.model, "accepts_context_key", False):
+            return self.model(x_noisy, t, context=cond, context_key=context_key)
         return self.model(x_noisy, t, context=cond)
+
+    accepts_context_key = True
 
 
 def _f32ptr(t, name):
@@ -145,10 +153,19 @@ class _LatentSampler:
         if bad:
             raise NotImplementedError(f"{type(self).__name__}: {bad} are not built on the HIP path (unused by search_ea.py)")
 
-    def _guided_input(self, x, t, c, uc, scale):
-        if uc is None or scale == 1.:
-            return x, t, c
-        return torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uc, c])
+    def _begin(self, c, uc, scale):
+        """Per sample() call: the guidance batch [uncond | cond] of the conditioning is built once, and models that
+        take a ``context_key`` (LatentDiffusion over the HIP UNet) are told that it stays fixed for the call's steps."""
+        self._guided = not (uc is None or scale == 1.)
+        self._c_in = torch.cat([uc, c]) if self._guided else c
+        self._key = ("sample", next(_CALL_IDS)) if getattr(self.model, "accepts_context_key", False) else None
+
+    def _eps(self, x, t):
+        if self._guided:
+            x, t = torch.cat([x] * 2), torch.cat([t] * 2)
+        if self._key is not None:
+            return self.model.apply_model(x, t, self._c_in, context_key=self._key)
+        return self.model.apply_model(x, t, self._c_in)
 
     def _start(self, shape, x_T):
         device = self.model.betas.device
@@ -182,6 +199,7 @@ class DDIMSampler(_LatentSampler):
     def _loop(self, cond, shape, x_T, callback, img_callback, log_every_t, temperature, unconditional_guidance_scale,
               unconditional_conditioning):
         device, img = self._start(shape, x_T)
+        self._begin(cond, unconditional_conditioning, unconditional_guidance_scale)
         b = shape[0]
         timesteps = np.asarray(self.ddim_timesteps)
         total = timesteps.shape[0]
@@ -189,8 +207,7 @@ class DDIMSampler(_LatentSampler):
         for i, step in enumerate(np.flip(timesteps)):
             index = total - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
-            eps = self.model.apply_model(*self._guided_input(img, ts, cond, unconditional_conditioning,
-                                                             unconditional_guidance_scale))
+            eps = self._eps(img, ts)
             sigma = self.ddim_sigmas[index]
             noise = torch.randn(shape, device=device) * temperature if sigma != 0 else None  # ddim.py:198 noise_like
             img, pred_x0, _ = sd_step(img, eps, b, unconditional_guidance_scale, (1.0,), (), self.ddim_alphas[index],
@@ -223,16 +240,17 @@ class PLMSSampler(_LatentSampler):
         time_range = np.flip(timesteps)
         intermediates = {'x_inter': [img], 'pred_x0': [img]}
         uc, scale = unconditional_conditioning, unconditional_guidance_scale
+        self._begin(cond, uc, scale)
         old_eps = []
         for i, step in enumerate(time_range):
             index = total - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
             ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), device=device, dtype=torch.long)
             a_t, a_prev, sigma = self.ddim_alphas[index], self.ddim_alphas_prev[index], self.ddim_sigmas[index]
-            eps = self.model.apply_model(*self._guided_input(img, ts, cond, uc, scale))
+            eps = self._eps(img, ts)
             if len(old_eps) == 0:    # pseudo improved Euler (2nd order): a second model call at the predicted point
                 x_mid, _, e_t = sd_step(img, eps, b, scale, (1.0,), (), a_t, a_prev, sigma)
-                eps2 = self.model.apply_model(*self._guided_input(x_mid, ts_next, cond, uc, scale))
+                eps2 = self._eps(x_mid, ts_next)
                 img, pred_x0, _ = sd_step(img, eps2, b, scale, (0.5, 0.5), (e_t,), a_t, a_prev, sigma, want_e=False)
             else:                    # Adams-Bashforth of order 2 / 3 / 4 over the kept eps history (newest first)
                 w = {1: (3 / 2, -1 / 2), 2: (23 / 12, -16 / 12, 5 / 12), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}[len(old_eps)]
@@ -330,9 +348,11 @@ class DPMSolverSampler(_LatentSampler):
         assert len(ts) - 1 == steps
         uc, scale = unconditional_conditioning, unconditional_guidance_scale
 
+        self._begin(conditioning, uc, scale)
+
         def eps_at(x_, t):  # model_wrapper: discrete-time input (t - 1/N) * 1000, guidance batch = [uncond | cond]
             t_in = torch.full((batch_size,), (t - 1.0 / ns.total_N) * 1000.0, device=device, dtype=torch.float32)
-            return self.model.apply_model(*self._guided_input(x_, t_in, conditioning, uc, scale))
+            return self._eps(x_, t_in)
 
         m_prev, lam_prev = None, None
         for step in range(1, steps + 1):

@@ -158,6 +158,7 @@ class UNetModel(HipModule):
         pr.zero_bias = torch.zeros(max(zmax, 32), dtype=torch.float32, device=dev)  # the bias-free Linear layers
         pr.head = dict(g=f32("out.0.weight"), b=f32("out.0.bias"), w=pack(P["out.2.weight"]), cb=f32("out.2.bias"))
         pr.graphs = {}  # captured evaluations; they die with the packed weights they point into
+        pr.kv_cache = None  # (context key, k|v projections of the cross-attention layers)
         self._packed = pr
         return pr
 
@@ -175,7 +176,7 @@ class UNetModel(HipModule):
             res = x0
         return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True)
 
-    def _transformer(self, pr, s: SDTransformerSpec, x, ctx_map, n_ctx):
+    def _transformer(self, pr, s: SDTransformerSpec, x, kvs, n_ctx):
         d = pr.blocks[s.prefix]
         n, hh, ww, c = x.shape
         t, heads, dp, inner = hh * ww, s.heads, d["dp"], s.inner
@@ -184,7 +185,7 @@ class UNetModel(HipModule):
         zb = pr.zero_bias
         aff = ops.gn_affine(x, d["g"], d["b"], eps=1e-6)
         h = ops.conv(x, d["w_in"], d["b_in"], inner, 1, aff=aff, silu=False)
-        for L in d["layers"]:
+        for li, L in enumerate(d["layers"]):
             # self-attention
             y = ops.layernorm(h, *L["norm1"])
             qkv = ops.conv(y, L["qkv1"], zb, 3 * hd, 1).view(n, t, 3 * hd)
@@ -193,7 +194,7 @@ class UNetModel(HipModule):
             # cross-attention over the conditioning tokens
             y = ops.layernorm(h, *L["norm2"])
             q = ops.conv(y, L["q2"], zb, hd, 1).view(n, t, hd)
-            kv = ops.conv(ctx_map, L["kv2"], zb, 2 * hd, 1)
+            kv = kvs[(s.prefix, li)]
             a = ops.attention_cross(q, kv.view(n, -1, 2 * hd), heads, dp, n_ctx, scale)
             h = ops.conv(a.view(n, hh, ww, hd), L["o2"], L["o2b"], inner, 1, res=h)
             # gated feed-forward
@@ -202,7 +203,7 @@ class UNetModel(HipModule):
             h = ops.conv(ops.geglu(u), L["ff2"], L["ff2b"], inner, 1, res=h)
         return ops.conv(h, d["w_out"], d["b_out"], c, 1, res=x, want_stats=True)
 
-    def _run_seq(self, pr, seq, h, skip, emb, ctx_map, n_ctx, x_nchw=None):
+    def _run_seq(self, pr, seq, h, skip, emb, kvs, n_ctx, x_nchw=None):
         first = True
         for blk in seq:
             d = pr.blocks[blk.prefix]
@@ -211,7 +212,7 @@ class UNetModel(HipModule):
             elif isinstance(blk, SDResBlockSpec):
                 h = self._resblock(pr, blk, h, skip if first else None, emb)
             elif isinstance(blk, SDTransformerSpec):
-                h = self._transformer(pr, blk, h, ctx_map, n_ctx)
+                h = self._transformer(pr, blk, h, kvs, n_ctx)
             elif isinstance(blk, SDDownSpec):
                 h = ops.resample(ops.conv(h, d["w"], d["b"], blk.channels, 9), "stride2")
             elif isinstance(blk, SDUpSpec):
@@ -231,52 +232,87 @@ class UNetModel(HipModule):
         self.use_graph = bool(flag)
         return self
 
-    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+    def _context_kv(self, pr, context, n):
+        """The k|v projections of every cross-attention layer: they depend on the conditioning only.  The tokens ride as a
+        bf16 pixel map (8x16 or 16x16, zero rows beyond S) so that the projections are 1x1 convs."""
+        plan: SDUNetPlan = self.plan
+        if context is None or context.dim() != 3 or context.shape[2] != plan.context_dim or context.shape[0] != n:
+            raise AdmError(f"context must be [N = {n}, S, {plan.context_dim}]")
+        s_ctx = context.shape[1]
+        if s_ctx > 256:
+            raise NotImplementedError("more than 256 conditioning tokens")
+        if not context.is_cuda:
+            raise AdmError("latent UNetModel.forward: context must be a device tensor (no CPU fallback)")
+        with torch.no_grad():
+            rows = 128 if s_ctx <= 128 else 256
+            ctx_map = torch.zeros((n, rows, plan.context_dim), dtype=torch.bfloat16, device=context.device)
+            ctx_map[:, :s_ctx] = context.to(torch.bfloat16)
+            ctx_map = ctx_map.view(n, rows // 16, 16, plan.context_dim)
+            kvs = {}
+            for b in plan.all_blocks():
+                if isinstance(b, SDTransformerSpec):
+                    d = pr.blocks[b.prefix]
+                    hd = b.heads * d["dp"]
+                    for li, L in enumerate(d["layers"]):
+                        kvs[(b.prefix, li)] = ops.conv(ctx_map, L["kv2"], pr.zero_bias, 2 * hd, 1)
+        return kvs
+
+    def _kv_for(self, pr, context, n, context_key):
+        """context_key: a token under which the CALLER guarantees the conditioning does not change (the samplers pass one
+        per sample() call: a candidate's K steps share their conditioning); None = recompute."""
+        if context_key is None:
+            return self._context_kv(pr, context, n), True
+        ck = (context_key, tuple(context.shape))
+        if pr.kv_cache is None or pr.kv_cache[0] != ck:
+            pr.kv_cache = (ck, self._context_kv(pr, context, n))
+            return pr.kv_cache[1], True
+        return pr.kv_cache[1], False
+
+    accepts_context_key = True
+
+    def forward(self, x, timesteps=None, context=None, y=None, context_key=None, **kwargs):
         """x fp32 [N, C, H, W] latents, timesteps [N], context [N, S, context_dim] -> fp32 [N, out, H, W]."""
-        if not self.use_graph:
-            return self._forward(x, timesteps, context, y)
         pr = self._packed or self._prepare()
-        if not (x.is_cuda and timesteps.is_cuda and context is not None and context.is_cuda):
-            raise AdmError("latent UNetModel (graph mode): x, timesteps and context must be device tensors")
-        key = (tuple(x.shape), x.dtype, tuple(timesteps.shape), timesteps.dtype, tuple(context.shape), context.dtype)
+        if not x.is_cuda:
+            raise AdmError("latent UNetModel.forward: x must be a device tensor (no CPU fallback)")
+        n = x.shape[0]
+        kvs, fresh = self._kv_for(pr, context, n, context_key)
+        if not self.use_graph:
+            return self._forward(x, timesteps, kvs, context.shape[1], y)
+        if not timesteps.is_cuda:
+            raise AdmError("latent UNetModel (graph mode): timesteps must be a device tensor")
+        key = (tuple(x.shape), x.dtype, tuple(timesteps.shape), timesteps.dtype, tuple(context.shape))
         entry = pr.graphs.get(key)
         if entry is None:
-            sx, st, sc = x.clone(), timesteps.clone(), context.clone()
+            sx, st = x.clone(), timesteps.clone()
+            skv = {k: v.clone() for k, v in kvs.items()}
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # first calls size per-kernel attributes; they must not land in the capture
                 for _ in range(2):
-                    self._forward(sx, st, sc, y)
+                    self._forward(sx, st, skv, context.shape[1], y)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                so = self._forward(sx, st, sc, y)
-            entry = pr.graphs[key] = (graph, sx, st, sc, so)
-        graph, sx, st, sc, so = entry
+                so = self._forward(sx, st, skv, context.shape[1], y)
+            entry = pr.graphs[key] = [graph, sx, st, skv, so, None]
+            fresh = True
+        graph, sx, st, skv, so, held = entry
         sx.copy_(x)
         st.copy_(timesteps)
-        sc.copy_(context)
+        if fresh or held is not kvs:  # the graph reads its own k|v buffers: refill them only when the conditioning changed
+            for k, v in kvs.items():
+                skv[k].copy_(v)
+            entry[5] = kvs if context_key is not None else None
         graph.replay()
         return so.clone()
 
-    def _forward(self, x, timesteps, context, y=None):
+    def _forward(self, x, timesteps, kvs, s_ctx, y=None):
         assert y is None, "must specify y if and only if the model is class-conditional"
         pr = self._packed or self._prepare()
         plan: SDUNetPlan = self.plan
-        if not x.is_cuda:
-            raise AdmError("latent UNetModel.forward: x must be a device tensor (no CPU fallback)")
-        if context is None or context.dim() != 3 or context.shape[2] != plan.context_dim:
-            raise AdmError(f"context must be [N, S, {plan.context_dim}]")
-        n, s_ctx = x.shape[0], context.shape[1]
-        if s_ctx > 256:
-            raise NotImplementedError("more than 256 conditioning tokens")
         x = x.to(torch.float32).contiguous()
         with torch.no_grad():
-            # conditioning tokens as a bf16 pixel map (8x16 or 16x16, zero rows beyond S): the k|v projections are 1x1 convs
-            rows = 128 if s_ctx <= 128 else 256
-            ctx_map = torch.zeros((n, rows, plan.context_dim), dtype=torch.bfloat16, device=x.device)
-            ctx_map[:, :s_ctx] = context.to(device=x.device, dtype=torch.bfloat16)
-            ctx_map = ctx_map.view(n, rows // 16, 16, plan.context_dim)
             e = ops.timestep_embedding(timesteps, plan.model_channels)
             e = ops.linear_f32(e, pr.te0_w, pr.te0_b)
             e = ops.linear_f32(e, pr.te2_w, pr.te2_b, silu_in=True)
@@ -284,11 +320,11 @@ class UNetModel(HipModule):
             hs: List[torch.Tensor] = []
             h = None
             for seq in plan.input_blocks:
-                h = self._run_seq(pr, seq, h, None, emb, ctx_map, s_ctx, x_nchw=x)
+                h = self._run_seq(pr, seq, h, None, emb, kvs, s_ctx, x_nchw=x)
                 hs.append(h)
-            h = self._run_seq(pr, plan.middle_block, h, None, emb, ctx_map, s_ctx)
+            h = self._run_seq(pr, plan.middle_block, h, None, emb, kvs, s_ctx)
             for seq in plan.output_blocks:
-                h = self._run_seq(pr, seq, h, hs.pop(), emb, ctx_map, s_ctx)
+                h = self._run_seq(pr, seq, h, hs.pop(), emb, kvs, s_ctx)
             hd = pr.head
             aff = ops.gn_affine(h, hd["g"], hd["b"])
             return ops.conv(h, hd["w"], hd["cb"], plan.out_channels, 9, aff=aff, silu=True, out_f32_nchw=True)

@@ -128,6 +128,15 @@ def test_sd_unet_matches_reference_golden(name):
     assert torch.equal(m(x, t, ctx), out)
     x2 = x.flip(0).contiguous() if x.shape[0] > 1 else x * 0.5
     assert torch.equal(m(x2, t, ctx), m.enable_graph(False)(x2, t, ctx))
+    # context_key: the k|v projections are computed once per key and reused (eager and graph mode), bit-identically
+    for graph in (False, True):
+        m.enable_graph(graph)
+        assert torch.equal(m(x, t, ctx, context_key="a"), out) and torch.equal(m(x, t, ctx, context_key="a"), out)
+        ctx2 = ctx * 0.5
+        want2 = m(x, t, ctx2)
+        assert not torch.equal(want2, out)
+        assert torch.equal(m(x, t, ctx2, context_key="b"), want2) and torch.equal(m(x, t, ctx, context_key="c"), out)
+    m.enable_graph(False)
     if name == "sd_unet_tiny":  # ragged batch reproduces per-image results
         out3 = m(torch.cat([x, x[:1]]), torch.cat([t, t[:1]]), torch.cat([ctx, ctx[:1]]))
         assert torch.equal(out3[:2], out) and torch.equal(out3[2], out[0])
