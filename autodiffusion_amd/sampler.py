@@ -13,6 +13,8 @@ out of scope: candidate evaluation never calls them.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -55,8 +57,15 @@ def step_coefs(tables, i: int, *, learned_range: bool, fixed: str = "large", pre
     return c
 
 
+_SIDE_STREAMS = {}  # device -> second HIP stream for the guidance gradient (kept out of the deep-copied objects)
+
+
 class SpacedDiffusion:
     """A diffusion process over a subset of a base process's timesteps (sampling only)."""
+
+    # eps(x_t) and the classifier-guidance gradient run concurrently on two HIP streams (bit-identical results;
+    # ADM_OVERLAP_GUIDANCE=0 or setting the attribute to False restores the sequential order)
+    overlap_guidance = os.environ.get("ADM_OVERLAP_GUIDANCE", "1") != "0"
 
     def __init__(self, use_timesteps, *, betas, model_mean_type, model_var_type, loss_type,
                  rescale_timesteps=False):
@@ -106,12 +115,26 @@ class SpacedDiffusion:
         i = index
         ts = self._mapped(t)
         x = x.contiguous()
-        model_out = model(x, ts, **model_kwargs)
+        grad = None
+        if cond_fn is not None and self.overlap_guidance and x.is_cuda:
+            # eps(x_t) and the guidance gradient both depend on x_t only: the gradient runs on a second HIP stream
+            # and fills the dispatch gaps and tile-quantisation tails of the UNet's ~2000 launches (and vice versa)
+            cur = torch.cuda.current_stream(x.device)
+            side = _SIDE_STREAMS.get(x.device)
+            if side is None:
+                side = _SIDE_STREAMS[x.device] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                grad = cond_fn(x, ts, **model_kwargs).float().contiguous()
+            model_out = model(x, ts, **model_kwargs)
+            cur.wait_stream(side)
+            grad.record_stream(cur)
+        else:
+            model_out = model(x, ts, **model_kwargs)
+            if cond_fn is not None:
+                grad = cond_fn(x, ts, **model_kwargs).float().contiguous()
         if model_out.dtype != torch.float32:
             model_out = model_out.float()
-        grad = None
-        if cond_fn is not None:
-            grad = cond_fn(x, ts, **model_kwargs).float().contiguous()
         # drawn every step, as the reference does (keeps the RNG stream aligned with it)
         if self.generator is not None:
             noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=self.generator)

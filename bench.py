@@ -272,6 +272,24 @@ def main():
                     "launches": len(dom), "avg_launch_us": round(ms * 1e3 / len(dom), 2),
                     "avg_launch_gflop": round(fl / len(dom) / 1e9, 3),
                     "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+            if guided and ev.active_diffusion.overlap_guidance:
+                # in the timed region the guidance gradient runs on a second stream, so the launches above share the CUs
+                # with its kernels (their event-bracketed time is not the kernel's own speed): one extra, untimed batch
+                # with the two networks in sequence gives the kernel's duration when it owns the chip
+                ev.active_diffusion.overlap_guidance = False
+                ops.CONV_PROFILE = []
+                one_step(args.steps)
+                torch.cuda.synchronize()
+                iso = [p for p in ops.CONV_PROFILE if p[3] == (5, 9, True, 2)]
+                ops.CONV_PROFILE = None
+                ev.active_diffusion.overlap_guidance = True
+                ims = sum(p[0].elapsed_time(p[1]) for p in iso)
+                ifl = sum(p[2] for p in iso)
+                roof["concurrency"] = "timed region: UNet and classifier-guidance kernels overlap on two HIP streams"
+                roof["isolated"] = {"achieved": round(ifl / (ims * 1e-3) / 1e12, 2),
+                                    "frac": round(ifl / (ims * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                    "avg_launch_us": round(ims * 1e3 / len(iso), 2), "launches": len(iso),
+                                    "how": "one untimed batch after the timed region, networks in sequence on one stream"}
 
     if rank == 0:
         imgs = world * B * args.steps

@@ -126,3 +126,20 @@ def test_unconditional_uniform_ddim4_and_return_all_images():
     assert len(imgs) == 5 and torch.equal(imgs[0], x_T)  # AutoDiffusion yields the start noise first
     dd = copy.deepcopy(diffusion)
     assert dd.num_timesteps == 4
+
+
+def test_two_stream_guidance_overlap_is_bit_identical():
+    """eps(x_t) on the launch stream and the guidance gradient on a second HIP stream (SpacedDiffusion.overlap_guidance,
+    the default) against the sequential order of the reference (gaussian_diffusion.py:258-326 then :381-393)."""
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    from autodiffusion_amd.sampler import SpacedDiffusion
+    assert SpacedDiffusion.overlap_guidance is True
+    model, diffusion, clf = _setup_m64()
+    outs = []
+    for use_ddim in (True, False):
+        for overlap in (True, False, True):
+            ev = CandidateEvaluator(model, diffusion, clf, image_size=64, use_ddim=use_ddim, device=DEV)
+            ev.set_candidate([153, 424, 926, 690])
+            ev.active_diffusion.overlap_guidance = overlap
+            outs.append(ev.sample_batch(5, seed=11).clone())
+        assert torch.equal(outs[-1], outs[-2]) and torch.equal(outs[-2], outs[-3])
