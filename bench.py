@@ -11,8 +11,9 @@ DDIM schedule [153, 424, 926, 690] through the ADM-G ImageNet-64 UNet (classifie
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...` (one rank per GPU, RCCL): the batch shards by image with no data-path collective
 (weak scaling); timing is barrier + synchronize bracketed, MAX over ranks.  Rank 0 prints ONE JSON
-line with the metric, the dominant kernel's roofline (HIP events on the launch stream) and the CPU
-oracle baseline timed on the host cores.
+line with the metric, the dominant kernel's roofline (HIP events on the launch stream; with classifier guidance
+the gradient network runs concurrently on a second stream, so `roofline.isolated` adds the kernel's launch time from
+one untimed batch with the two networks in sequence) and the CPU oracle baseline timed on the host cores.
 """
 import argparse
 import json
