@@ -339,8 +339,8 @@ extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse,
                                  int new_order, void* stream) {
   ADM_REQUIRE(qkv && out, ADM_E_ARG, "adm_attention: null pointer");
   ADM_REQUIRE(n > 0 && t > 0 && heads > 0, ADM_E_ARG, "adm_attention: bad shape n=%d t=%d heads=%d", n, t, heads);
-  ADM_REQUIRE(d == 32 || d == 64 || d == 128 || d == 192 || d == 256, ADM_E_SHAPE,
-              "adm_attention: head dim %d unsupported (32, 64, 128, 192, 256)", d);
+  ADM_REQUIRE(d == 32 || d == 64 || d == 96 || d == 128 || d == 160 || d == 192 || d == 256, ADM_E_SHAPE,
+              "adm_attention: head dim %d unsupported (32, 64, 96, 128, 160, 192, 256)", d);
   ADM_REQUIRE(adm_aligned16(qkv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention: unaligned pointer");
   ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention: n*heads exceeds grid.y");
   AttnK k{};
@@ -358,8 +358,8 @@ extern "C" int adm_attention_cross(const adm_bf16* q, int q_stride, const adm_bf
   ADM_REQUIRE(q && kv && out, ADM_E_ARG, "adm_attention_cross: null pointer");
   ADM_REQUIRE(n > 0 && tq > 0 && tk > 0 && heads > 0 && kv_rows >= tk, ADM_E_ARG,
               "adm_attention_cross: bad shape n=%d tq=%d tk=%d kv_rows=%d heads=%d", n, tq, tk, kv_rows, heads);
-  ADM_REQUIRE(d == 32 || d == 64 || d == 128 || d == 192 || d == 256, ADM_E_SHAPE,
-              "adm_attention_cross: head dim %d unsupported (32, 64, 128, 192, 256)", d);
+  ADM_REQUIRE(d == 32 || d == 64 || d == 96 || d == 128 || d == 160 || d == 192 || d == 256, ADM_E_SHAPE,
+              "adm_attention_cross: head dim %d unsupported (32, 64, 96, 128, 160, 192, 256)", d);
   ADM_REQUIRE(q_stride >= heads * d && kv_stride >= 2 * heads * d && q_stride % 8 == 0 && kv_stride % 8 == 0, ADM_E_SHAPE,
               "adm_attention_cross: row pitches %d / %d too small or not multiples of 8", q_stride, kv_stride);
   ADM_REQUIRE(adm_aligned16(q) && adm_aligned16(kv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention_cross: unaligned pointer");
@@ -381,12 +381,14 @@ int launch_attention(const AttnK& k, int n, int t, int heads, int d, hipStream_t
   dim3 grid((t + QB - 1) / QB, n * heads);
   if (d > 128) {
     dim3 gridw((t + 63) / 64, n * heads);
-    if (d == 192) hipLaunchKernelGGL((attn_wide_kernel<192>), gridw, dim3(256), 0, s, k);
+    if (d == 160) hipLaunchKernelGGL((attn_wide_kernel<160>), gridw, dim3(256), 0, s, k);
+    else if (d == 192) hipLaunchKernelGGL((attn_wide_kernel<192>), gridw, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((attn_wide_kernel<256>), gridw, dim3(256), 0, s, k);
     return adm_check_launch("adm_attention");
   }
   if (d == 32) hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, k);
   else if (d == 64) hipLaunchKernelGGL((attn_kernel<64>), grid, dim3(256), 0, s, k);
+  else if (d == 96) hipLaunchKernelGGL((attn_kernel<96>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, k);
   return adm_check_launch("adm_attention");
 }

@@ -17,8 +17,9 @@ Engine: activations are bf16 NHWC, so a token of the SpatialTransformer IS a pix
       LayerNorm -> fused q|k|v 1x1 -> attention -> 1x1 to_out (+x)
       LayerNorm -> 1x1 to_q; context -> 1x1 k|v (77 tokens padded to a 8x16 map) -> attention -> 1x1 to_out (+x)
       LayerNorm -> 1x1 (C -> 8C) -> GEGLU -> 1x1 (4C -> C) (+x);  1x1 proj_out (+x_in)
-  The reference's 40 / 80 / 160-channel heads are zero-padded to 64 / 128 / 192 by the packed projection weights (the
-  MFMA attention kernels take head widths 32/64/128/192/256); the logit scale stays dim_head^-0.5.
+  The reference's 40 / 80-channel heads are zero-padded to 64 / 96 by the packed projection weights (the MFMA
+  attention kernels take head widths that are multiples of 32 up to 256: 160 runs as it is); the logit scale stays
+  dim_head^-0.5.
 """
 from __future__ import annotations
 
@@ -32,7 +33,7 @@ from .sd_arch import (SDDownSpec, SDResBlockSpec, SDStemSpec, SDTransformerSpec,
                       sd_unet_plan)
 from .unet import HipModule, _Prep
 
-_HEAD_WIDTHS = (32, 64, 128, 192, 256)
+_HEAD_WIDTHS = (32, 64, 96, 128, 160, 192, 256)
 
 
 def _padded_head(d: int) -> int:

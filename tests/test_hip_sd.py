@@ -59,6 +59,8 @@ def test_geglu(rows, inner):
 @pytest.mark.parametrize("n,tq,tk,rows,heads,d,true_d", [
     (2, 256, 77, 128, 8, 64, 40),     # cross-attention of the 320-channel level (40-wide heads padded to 64)
     (1, 1024, 77, 128, 8, 128, 80),
+    (2, 1024, 77, 128, 8, 96, 80),    # 80-wide heads padded to 96
+    (1, 256, 77, 128, 8, 160, 160),   # 160-wide heads as they are
     (2, 64, 7, 128, 2, 32, 32),
     (1, 256, 77, 128, 8, 192, 160),
     (3, 100, 130, 256, 4, 64, 64),    # ragged on both sides, more than one key tile
