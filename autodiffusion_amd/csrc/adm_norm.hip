@@ -144,11 +144,22 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
     const bool first = ch < c0;
     const float* base = first ? part0 : part1;
     const int cs = first ? c0 : c1, cl = first ? ch : ch - c0, slabs = first ? slabs0 : slabs1;
+    // the launch is a few hundred dependent-latency loads long, not bandwidth: 8-byte loads, four slabs in flight
     double cs1 = 0.0, cs2 = 0.0;
-    for (int sl = 0; sl < slabs; ++sl) {
-      const float* p = base + ((((long long)img * slabs + sl) * cs) + cl) * 2;
-      cs1 += (double)p[0];
-      cs2 += (double)p[1];
+    const float2* p = reinterpret_cast<const float2*>(base + (((long long)img * slabs) * cs + cl) * 2);
+    int sl = 0;
+    for (; sl + 4 <= slabs; sl += 4) {
+      const float2 v0 = p[(long long)sl * cs], v1 = p[(long long)(sl + 1) * cs], v2 = p[(long long)(sl + 2) * cs],
+                   v3 = p[(long long)(sl + 3) * cs];
+      cs1 += (double)v0.x; cs2 += (double)v0.y;
+      cs1 += (double)v1.x; cs2 += (double)v1.y;
+      cs1 += (double)v2.x; cs2 += (double)v2.y;
+      cs1 += (double)v3.x; cs2 += (double)v3.y;
+    }
+    for (; sl < slabs; ++sl) {
+      const float2 v = p[(long long)sl * cs];
+      cs1 += (double)v.x;
+      cs2 += (double)v.y;
     }
     if (add) {  // statistics of x + e[img, ch] from those of x: sum += hw*e, sum of squares += 2*e*sum + hw*e^2
       const double e = (double)add[(long long)img * add_stride + ch];
