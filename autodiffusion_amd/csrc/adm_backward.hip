@@ -90,14 +90,19 @@ gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restric
   const int cpg = c / 32;
   const int grp = threadIdx.x / 8, sub = threadIdx.x % 8;
   const float mean = stats[((long long)img * 32 + grp) * 2 + 0], rstd = stats[((long long)img * 32 + grp) * 2 + 1];
+  // a latency-bound launch: no divisions in the loop (1/rstd is applied to the sum), 8-byte loads
   double s1 = 0.0, s2 = 0.0;
+  int sl = sub / cpg, j = sub % cpg;
   for (int i = sub; i < slabs * cpg; i += 8) {
-    const int sl = i / cpg, ch = grp * cpg + i % cpg;
-    const float* p = partial + ((((long long)img * slabs + sl) * c) + ch) * 2;
+    const int ch = grp * cpg + j;
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((((long long)img * slabs + sl) * c) + ch) * 2);
     const double a = (double)aa[(long long)img * c + ch];
-    s1 += a / (double)rstd * (double)p[0];
-    s2 += a * ((double)p[1] - (double)mean * (double)p[0]);
+    s1 += a * (double)v.x;
+    s2 += a * ((double)v.y - (double)mean * (double)v.x);
+    j += 8;
+    while (j >= cpg) { j -= cpg; ++sl; }
   }
+  s1 /= (double)rstd;
 #pragma unroll
   for (int off = 4; off >= 1; off >>= 1) {
     s1 += __shfl_xor(s1, off);
