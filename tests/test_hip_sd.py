@@ -64,6 +64,10 @@ def test_geglu(rows, inner):
     (2, 64, 7, 128, 2, 32, 32),
     (1, 256, 77, 128, 8, 192, 160),
     (3, 100, 130, 256, 4, 64, 64),    # ragged on both sides, more than one key tile
+    (1, 1, 1, 128, 1, 32, 32),        # a single query over a single key
+    (2, 33, 64, 64, 2, 64, 64),       # exactly one key tile, kv_rows == tk
+    (2, 65, 65, 128, 3, 96, 80),      # one key / one query past a tile boundary
+    (1, 17, 200, 256, 2, 160, 160),   # wide kernel, several ragged key tiles
 ])
 def test_attention_cross(n, tq, tk, rows, heads, d, true_d):
     from autodiffusion_amd import ops
