@@ -23,7 +23,8 @@ USE_FUSED_STATS = True
 
 # bench.py sets this to a list to time the dominant kernel with HIP events on the launch stream:
 # every conv launch appends (start_event, end_event, algorithmic_flops, (variant, taps, big_map, prologue)).
-CONV_PROFILE = None
+CONV_PROFILE = None       # bench.py: list receiving (event0, event1, flops, key, shape) per conv launch
+CONV_PROFILE_KEY = None   # ... restricted to launches with this (variant, taps, big map, prologue) key
 
 
 def _stream() -> int:
@@ -265,7 +266,7 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
             fused = (torch.empty((n, slabs, cout, 2), dtype=torch.float32, device=dev), slabs)
             a.out_stats = fused[0].data_ptr()
             out._adm_stats = fused
-    if CONV_PROFILE is not None:
+    if CONV_PROFILE is not None and (CONV_PROFILE_KEY is None or CONV_PROFILE_KEY == (variant, taps, h * w > 64, a.prologue)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")

@@ -230,6 +230,9 @@ def main():
         dist.barrier()
     if not args.no_kernel_events:
         ops.CONV_PROFILE = []
+        # HIP events only around the dominant kernel's launches (all conv launches with --conv-breakdown): a pair of
+        # events per launch costs the unguided workload 3.5 % when every conv carries one
+        ops.CONV_PROFILE_KEY = None if args.conv_breakdown else (5, 9, True, 2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
