@@ -38,9 +38,13 @@ struct AttnK {
 template <int D>
 __global__ void __launch_bounds__(256, D <= 64 ? 2 : 0)
 attn_kernel(const AttnK p) {
-  constexpr int KS = D / 32;   // k-steps of QK^T
+  constexpr int KS = D / 32;   // 32-deep k-steps of QK^T
+  constexpr bool R16 = (D % 32) == 16;  // plus one 16-deep step (v_mfma_f32_16x16x16_bf16): head widths 48, 80, 112
+  static_assert(D % 16 == 0 && KS >= 1, "head width must be a multiple of 16, at least 32");
   constexpr int DT = D / 16;   // d tiles of the output
-  constexpr int KROW = D + PADE;
+  // LDS row pitch = 8 mod 16 dwords (conflict-free for the b128 fragment reads and the transposing reads): 48- and
+  // 80-wide heads have it unpadded (24 / 40 dwords), the multiples of 32 need the 16-element pad
+  constexpr int KROW = D + (((D / 2) % 16 == 8) ? 0 : PADE);
   // K and V tiles row-major, double-buffered: the next tile's global loads fly during this tile's MFMAs
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KT * KROW];
   __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KT * KROW];
@@ -68,6 +72,15 @@ attn_kernel(const AttnK p) {
     for (int ks = 0; ks < KS; ++ks) {
       const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
       qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  adm_s16x4 qf16[2] = {};  // the 16-deep tail: lane (query lc, quarter lq) holds Q[query][32*KS + 4*lq .. +4]
+  if constexpr (R16) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qbase + qt * 16 + lc;
+      const adm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (q * p.C3 + qcol + KS * 32 + lq * 4) * 2, 0, 0);
+      qf16[qt] = __builtin_bit_cast(adm_s16x4, v);
     }
   }
 
@@ -108,6 +121,12 @@ attn_kernel(const AttnK p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         kfr[kt][ks] = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+    adm_s16x4 kfr16[4] = {};
+    if constexpr (R16) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        kfr16[kt] = *reinterpret_cast<const adm_s16x4*>(&Kc[(kt * 16 + lc) * KROW + KS * 32 + lq * 4]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     f32x4 st[4][2];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -121,6 +140,11 @@ attn_kernel(const AttnK p) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
+      if constexpr (R16) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kfr16[kt], qf16[qt], st[kt][qt], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 vfr[DT][2];
@@ -339,8 +363,8 @@ extern "C" int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse,
                                  int new_order, void* stream) {
   ADM_REQUIRE(qkv && out, ADM_E_ARG, "adm_attention: null pointer");
   ADM_REQUIRE(n > 0 && t > 0 && heads > 0, ADM_E_ARG, "adm_attention: bad shape n=%d t=%d heads=%d", n, t, heads);
-  ADM_REQUIRE(d == 32 || d == 64 || d == 96 || d == 128 || d == 160 || d == 192 || d == 256, ADM_E_SHAPE,
-              "adm_attention: head dim %d unsupported (32, 64, 96, 128, 160, 192, 256)", d);
+  ADM_REQUIRE(d == 32 || d == 48 || d == 64 || d == 80 || d == 96 || d == 128 || d == 160 || d == 192 || d == 256, ADM_E_SHAPE,
+              "adm_attention: head dim %d unsupported (32, 48, 64, 80, 96, 128, 160, 192, 256)", d);
   ADM_REQUIRE(adm_aligned16(qkv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention: unaligned pointer");
   ADM_REQUIRE((long long)n * heads < 65536, ADM_E_SHAPE, "adm_attention: n*heads exceeds grid.y");
   AttnK k{};
@@ -358,8 +382,8 @@ extern "C" int adm_attention_cross(const adm_bf16* q, int q_stride, const adm_bf
   ADM_REQUIRE(q && kv && out, ADM_E_ARG, "adm_attention_cross: null pointer");
   ADM_REQUIRE(n > 0 && tq > 0 && tk > 0 && heads > 0 && kv_rows >= tk, ADM_E_ARG,
               "adm_attention_cross: bad shape n=%d tq=%d tk=%d kv_rows=%d heads=%d", n, tq, tk, kv_rows, heads);
-  ADM_REQUIRE(d == 32 || d == 64 || d == 96 || d == 128 || d == 160 || d == 192 || d == 256, ADM_E_SHAPE,
-              "adm_attention_cross: head dim %d unsupported (32, 64, 96, 128, 160, 192, 256)", d);
+  ADM_REQUIRE(d == 32 || d == 48 || d == 64 || d == 80 || d == 96 || d == 128 || d == 160 || d == 192 || d == 256, ADM_E_SHAPE,
+              "adm_attention_cross: head dim %d unsupported (32, 48, 64, 80, 96, 128, 160, 192, 256)", d);
   ADM_REQUIRE(q_stride >= heads * d && kv_stride >= 2 * heads * d && q_stride % 8 == 0 && kv_stride % 8 == 0, ADM_E_SHAPE,
               "adm_attention_cross: row pitches %d / %d too small or not multiples of 8", q_stride, kv_stride);
   ADM_REQUIRE(adm_aligned16(q) && adm_aligned16(kv) && adm_aligned16(out), ADM_E_ALIGN, "adm_attention_cross: unaligned pointer");
@@ -387,6 +411,8 @@ int launch_attention(const AttnK& k, int n, int t, int heads, int d, hipStream_t
     return adm_check_launch("adm_attention");
   }
   if (d == 32) hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, k);
+  else if (d == 48) hipLaunchKernelGGL((attn_kernel<48>), grid, dim3(256), 0, s, k);
+  else if (d == 80) hipLaunchKernelGGL((attn_kernel<80>), grid, dim3(256), 0, s, k);
   else if (d == 64) hipLaunchKernelGGL((attn_kernel<64>), grid, dim3(256), 0, s, k);
   else if (d == 96) hipLaunchKernelGGL((attn_kernel<96>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((attn_kernel<128>), grid, dim3(256), 0, s, k);

@@ -17,8 +17,8 @@ Engine: activations are bf16 NHWC, so a token of the SpatialTransformer IS a pix
       LayerNorm -> fused q|k|v 1x1 -> attention -> 1x1 to_out (+x)
       LayerNorm -> 1x1 to_q; context -> 1x1 k|v (77 tokens padded to a 8x16 map) -> attention -> 1x1 to_out (+x)
       LayerNorm -> 1x1 (C -> 8C) -> GEGLU -> 1x1 (4C -> C) (+x);  1x1 proj_out (+x_in)
-  The reference's 40 / 80-channel heads are zero-padded to 64 / 96 by the packed projection weights (the MFMA
-  attention kernels take head widths that are multiples of 32 up to 256: 160 runs as it is); the logit scale stays
+  The reference's 40-channel heads are zero-padded to 48 by the packed projection weights (the MFMA attention kernels
+  take head widths 32, 48, 64, 80, 96, 128, 160, 192, 256: 80 and 160 run as they are); the logit scale stays
   dim_head^-0.5.
 """
 from __future__ import annotations
@@ -33,7 +33,7 @@ from .sd_arch import (SDDownSpec, SDResBlockSpec, SDStemSpec, SDTransformerSpec,
                       sd_unet_plan)
 from .unet import HipModule, _Prep
 
-_HEAD_WIDTHS = (32, 64, 96, 128, 160, 192, 256)
+_HEAD_WIDTHS = (32, 48, 64, 80, 96, 128, 160, 192, 256)
 
 
 def _padded_head(d: int) -> int:

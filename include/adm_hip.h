@@ -181,7 +181,7 @@ int adm_pack_conv_weight(const float* w, adm_bf16* out, int cout, int cin, int t
  * qkv bf16 [N][T][3*H*D] (token-major, the 1x1 qkv conv's NHWC output) -> out bf16 [N][T][H*D];
  * softmax in fp32 over all T keys, logits scaled by 1/sqrt(D) (= the reference's
  * ch^-1/4 on q and on k).  new_order 1: channels are [3][H][D]; 0 (legacy): [H][3][D].
- * D in {32, 64, 96, 128} (tuned path) or {160, 192, 256} (ADM-128 / SD wide heads: sized to fit, not tuned). */
+ * D in {32, 48, 64, 80, 96, 128} (tuned path; 48 / 80 add one 16-deep MFMA step) or {160, 192, 256} (ADM-128 / SD wide heads: sized to fit, not tuned). */
 int adm_attention(const adm_bf16* qkv, adm_bf16* out, int n, int t, int heads, int d,
                   int new_order, void* stream);
 
@@ -196,8 +196,8 @@ int adm_attention_lse(const adm_bf16* qkv, adm_bf16* out, float* lse, int n, int
  *   q   bf16 [N][tq][q_stride]       head h = columns h*d .. h*d+d
  *   kv  bf16 [N][kv_rows][kv_stride] K head h = columns h*d .., V head h = columns heads*d + h*d ..; only the first
  *                                    tk rows of every image are attended to (kv_rows >= tk is the row pitch)
- *   out bf16 [N][tq][heads*d];  scale <= 0 selects 1/sqrt(d).  d in {32, 64, 96, 128, 160, 192, 256}: other reference head
- *   widths (40 / 80 channels) are zero-padded by the caller's projection weights, with scale = true_dim^-0.5.     */
+ *   out bf16 [N][tq][heads*d];  scale <= 0 selects 1/sqrt(d).  d in {32, 48, 64, 80, 96, 128, 160, 192, 256}: other reference
+ *   head widths (SD's 40 channels) are zero-padded by the caller's projection weights, with scale = true_dim^-0.5.     */
 int adm_attention_cross(const adm_bf16* q, int q_stride, const adm_bf16* kv, int kv_stride, int kv_rows,
                         adm_bf16* out, int n, int tq, int tk, int heads, int d, float scale, void* stream);
 

@@ -60,6 +60,9 @@ def test_geglu(rows, inner):
     (2, 256, 77, 128, 8, 64, 40),     # cross-attention of the 320-channel level (40-wide heads padded to 64)
     (1, 1024, 77, 128, 8, 128, 80),
     (2, 1024, 77, 128, 8, 96, 80),    # 80-wide heads padded to 96
+    (2, 512, 77, 128, 8, 48, 40),     # 40-wide heads padded to 48: one 32-deep + one 16-deep MFMA step
+    (1, 1024, 1024, 1024, 8, 80, 80), # 80-wide heads as they are, long keys
+    (3, 70, 130, 256, 2, 48, 40),     # ... ragged
     (1, 256, 77, 128, 8, 160, 160),   # 160-wide heads as they are
     (2, 64, 7, 128, 2, 32, 32),
     (1, 256, 77, 128, 8, 192, 160),

@@ -123,9 +123,9 @@ def test_sd_samplers_fail_loudly_without_a_gpu():
 def test_sd_unet_head_padding_is_exact():
     """Zero-padding the 40-channel heads to 64 inside the projection weights leaves q.k and the output unchanged."""
     from autodiffusion_amd.sd_unet import _pad_heads_in, _pad_heads_out, _padded_head
-    assert [_padded_head(d) for d in (32, 40, 64, 80, 160, 256)] == [32, 64, 64, 96, 160, 256]
+    assert [_padded_head(d) for d in (32, 40, 64, 80, 160, 256)] == [32, 48, 64, 80, 160, 256]
     g = torch.Generator().manual_seed(0)
-    heads, d, dp, cin, t = 8, 40, 64, 320, 5
+    heads, d, dp, cin, t = 8, 40, 48, 320, 5
     wq, wk, wv = (torch.randn(heads * d, cin, generator=g) * cin ** -0.5 for _ in range(3))
     wo = torch.randn(cin, heads * d, generator=g) * cin ** -0.5
     x = torch.randn(t, cin, generator=g)
