@@ -89,6 +89,66 @@ linear_kernel(const float* __restrict__ in, const float* __restrict__ w, const f
   }
 }
 
+
+// Few rows (n <= 64: the Stable-Diffusion UNet evaluates 12 latents): a GEMV-shaped pass.  The 64 x 64 tile kernel above
+// leaves most of its rows empty and crawls through K behind two barriers per 16-deep step; here a block keeps 16 input rows
+// (activation applied) in LDS, each wave streams whole weight rows with 16-byte lanes (every weight is read once per 16
+// rows) and reduces 16 dot products per output column across its lanes.
+constexpr int LS_ROWS = 16, LS_CPW = 8;  // rows per block, output columns per wave
+
+template <bool SILU>
+__global__ void __launch_bounds__(256)
+linear_small_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                    const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
+                    int n, int k, int o) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [LS_ROWS][k]
+  const int r0 = blockIdx.y * LS_ROWS;
+  const int nr = min(LS_ROWS, n - r0);
+  for (int i = threadIdx.x; i < LS_ROWS * k; i += 256) {
+    const int r = i / k, kk = i - r * k;
+    float v = 0.0f;
+    if (r < nr) {
+      v = in[(long long)(r0 + r) * k + kk];
+      if (SILU) v = adm_silu(v);
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col0 = (blockIdx.x * 4 + wave) * LS_CPW;
+  for (int c = 0; c < LS_CPW; ++c) {
+    const int col = col0 + c;
+    if (col >= o) break;  // wave-uniform
+    float acc[LS_ROWS];
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; ++r) acc[r] = 0.0f;
+    const float* wrow = w + (long long)col * k;
+    for (int kk = lane * 4; kk < k; kk += 256) {
+      const float4 wv = *reinterpret_cast<const float4*>(wrow + kk);
+#pragma unroll
+      for (int r = 0; r < LS_ROWS; ++r) {
+        const float4 xv = *reinterpret_cast<const float4*>(xs + r * k + kk);
+        acc[r] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; ++r) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc[r] += __shfl_xor(acc[r], off);
+    }
+    float mine = 0.0f;  // lane r keeps row r's sum
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; ++r)
+      if (lane == r) mine = acc[r];
+    if (lane < nr) {
+      const int row = r0 + lane;
+      float v = mine + (bias ? bias[col] : 0.0f);
+      if (table) v += table[(long long)idx[row] * o + col];
+      out[(long long)row * o + col] = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int adm_timestep_embedding(const float* t, float* out, int n, int dim, float max_period, void* stream) {
@@ -107,8 +167,26 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
   ADM_REQUIRE(in && w && out, ADM_E_ARG, "adm_linear_f32: null pointer");
   ADM_REQUIRE(n > 0 && k > 0 && o > 0, ADM_E_ARG, "adm_linear_f32: bad shape n=%d k=%d o=%d", n, k, o);
   ADM_REQUIRE((table == nullptr) == (idx == nullptr), ADM_E_ARG, "adm_linear_f32: table and idx go together");
-  dim3 grid((o + LT - 1) / LT, (n + LT - 1) / LT);
   hipStream_t s = (hipStream_t)stream;
+  const size_t small_lds = (size_t)LS_ROWS * k * sizeof(float);
+  if (n <= 64 && k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
+    static bool attr_set[64][2] = {};  // per device: opt in to the dynamic LDS size once per instantiation
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& done = attr_set[dev & 63][silu_in ? 1 : 0];
+    if (!done) {
+      const void* fn = silu_in ? reinterpret_cast<const void*>(&linear_small_kernel<true>)
+                               : reinterpret_cast<const void*>(&linear_small_kernel<false>);
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) ADM_FAIL((int)e, "adm_linear_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      done = true;
+    }
+    dim3 g((o + 4 * LS_CPW - 1) / (4 * LS_CPW), (n + LS_ROWS - 1) / LS_ROWS);
+    if (silu_in) hipLaunchKernelGGL((linear_small_kernel<true>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
+    else hipLaunchKernelGGL((linear_small_kernel<false>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
+    return adm_check_launch("adm_linear_f32");
+  }
+  dim3 grid((o + LT - 1) / LT, (n + LT - 1) / LT);
   if (silu_in) hipLaunchKernelGGL((linear_kernel<true>), grid, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
   else hipLaunchKernelGGL((linear_kernel<false>), grid, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
   return adm_check_launch("adm_linear_f32");
