@@ -128,7 +128,12 @@ linear_small_kernel(const float* __restrict__ in, const float* __restrict__ w, c
 #pragma unroll
       for (int r = 0; r < LS_ROWS; ++r) {
         const float4 xv = *reinterpret_cast<const float4*>(xs + r * k + kk);
-        acc[r] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+        // explicit fma chain: left to contraction, the unrolled rows were not all fused the same way and a row's
+        // result depended on its position in the block (batch-slice invariance is tested bitwise)
+        acc[r] = __builtin_fmaf(wv.x, xv.x, acc[r]);
+        acc[r] = __builtin_fmaf(wv.y, xv.y, acc[r]);
+        acc[r] = __builtin_fmaf(wv.z, xv.z, acc[r]);
+        acc[r] = __builtin_fmaf(wv.w, xv.w, acc[r]);
       }
     }
 #pragma unroll

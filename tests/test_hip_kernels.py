@@ -123,6 +123,8 @@ def test_linear_f32(ops, n, k, o):
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
     got = ops.linear_f32(x.to(DEV), w.to(DEV), None).cpu()
     torch.testing.assert_close(got, F.linear(x, w), rtol=1e-4, atol=1e-4)
+    if n >= 4 and (n <= 64) == (n - n // 2 <= 64):  # a row's result does not depend on where it sits in the batch (same kernel)
+        assert torch.equal(ops.linear_f32(x[n // 2:].contiguous().to(DEV), w.to(DEV), None).cpu(), got[n // 2:])
 
 
 # ------------------------------------------------------------------ stem / GN / resample
