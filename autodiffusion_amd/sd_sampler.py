@@ -26,33 +26,33 @@ _CALL_IDS = itertools.count()  # one id per sample() call in this process: the c
 
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
-    """ldm/modules/diffusionmodules/util.py:21-43 (float64)."""
-    if schedule == "linear":
-        betas = np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
-    elif schedule == "cosine":
-        ts = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
-        al = np.cos(ts / (1 + cosine_s) * np.pi / 2) ** 2
-        al = al / al[0]
-        betas = np.clip(1 - al[1:] / al[:-1], 0, 0.999)
-    elif schedule == "sqrt_linear":
-        betas = np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
-    elif schedule == "sqrt":
-        betas = np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64) ** 0.5
-    else:
-        raise ValueError(f"schedule '{schedule}' unknown.")
-    return betas
+    """The four named beta schedules of ldm/modules/diffusionmodules/util.py:21-43, float64 numpy."""
+    grid = lambda lo, hi: np.linspace(lo, hi, n_timestep, dtype=np.float64)  # noqa: E731
+    if schedule == "linear":        # linear in sqrt(beta): the latent-diffusion default
+        return grid(linear_start ** 0.5, linear_end ** 0.5) ** 2
+    if schedule == "sqrt_linear":
+        return grid(linear_start, linear_end)
+    if schedule == "sqrt":
+        return grid(linear_start, linear_end) ** 0.5
+    if schedule == "cosine":
+        t = np.arange(n_timestep + 1, dtype=np.float64) / n_timestep + cosine_s
+        abar = np.cos(t / (1 + cosine_s) * np.pi / 2) ** 2
+        abar /= abar[0]
+        return np.clip(1 - abar[1:] / abar[:-1], 0, 0.999)
+    raise ValueError(f"schedule '{schedule}' unknown.")
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
-    """util.py:46-63 (the reference rounds the stride, it does not floor it)."""
+    """util.py:46-63: the fallback grid when no searched list is given.  The reference ROUNDS the stride (it does not
+    floor it) and shifts every step by one."""
     if ddim_discr_method == "uniform":
-        c = round(num_ddpm_timesteps / num_ddim_timesteps)
-        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+        stride = round(num_ddpm_timesteps / num_ddim_timesteps)
+        steps = np.arange(0, num_ddpm_timesteps, stride)
     elif ddim_discr_method == "quad":
-        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+        steps = (np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps) ** 2).astype(int)
     else:
         raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
-    return ddim_timesteps + 1
+    return steps + 1
 
 
 def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
