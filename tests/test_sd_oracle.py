@@ -139,3 +139,27 @@ def test_sd_unet_head_padding_is_exact():
     got = attn(_pad_heads_out(wq, heads, d, dp), _pad_heads_out(wk, heads, d, dp), _pad_heads_out(wv, heads, d, dp),
                _pad_heads_in(wo, heads, d, dp), dp)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_sd_unet_module_surface_on_the_cpu():
+    """Constructor bookkeeping and the nn.Module-like surface need no GPU; the forward fails loudly without one."""
+    from autodiffusion_amd._lib import AdmError
+    from autodiffusion_amd.sd_unet import UNetModel
+    m = UNetModel(image_size=32, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[1, 2],
+                  num_res_blocks=1, channel_mult=[1, 2], num_heads=2, use_spatial_transformer=True, transformer_depth=1,
+                  context_dim=96, use_checkpoint=True, legacy=False)
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 4_237_956  # the reference module's count (capture_sd.py printed it)
+    assert m.accepts_context_key and m.num_classes is None
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: v for k, v in list(sd.items())[1:]})          # a missing key
+    bad = dict(sd)
+    bad["out.2.bias"] = torch.zeros(5)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)                                              # a shape mismatch
+    m.load_state_dict(sd)
+    with pytest.raises(AdmError):
+        m(torch.zeros(1, 4, 16, 16), torch.zeros(1, dtype=torch.int64), torch.zeros(1, 3, 96))  # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        UNetModel(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[1],
+                  num_heads=2, use_spatial_transformer=False, context_dim=None)
