@@ -77,10 +77,17 @@ class EncoderUNetModel(AdmNet):
         return logits
 
     def forward(self, x, timesteps):
-        """x fp32 [N,3,H,W], timesteps [N] -> logits fp32 [N, 1000]."""
+        """x fp32 [N,3,H,W], timesteps [N] -> logits fp32 [N, 1000].
+
+        If ``x`` requires grad (inside ``th.enable_grad()``), the logits carry a torch.autograd node whose backward
+        runs the explicit backward-data network: the reference's own ``cond_fn`` closure
+        (search_imagenet64_classifier_guidance.py:319-326 -- ``classifier(x_in, t)``, ``log_softmax``, ``autograd.grad``)
+        works unchanged on this object."""
         pr = self._packed or self._prepare()
         if not x.is_cuda:
             raise AdmError("EncoderUNetModel.forward: x must be a device tensor (no CPU fallback)")
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _ClassifierFn.apply(x, timesteps, self)
         with torch.no_grad():
             x = x.to(torch.float32).contiguous()
             return self._head_forward(pr, self._features(pr, x, timesteps, None), None)
@@ -89,21 +96,24 @@ class EncoderUNetModel(AdmNet):
     def _bwd_conv(self, pr, dy, w_bwd, cout, taps):
         return ops.conv(dy, w_bwd, pr.zero_bias, cout, taps)
 
-    def log_prob_grad(self, x, timesteps, y, scale: float = 1.0, return_logits: bool = False):
-        """scale * grad_x sum_n log_softmax(f(x,t))[n, y_n]; fp32 [N,3,H,W]."""
+    def _forward_tape(self, x, timesteps):
+        """Forward with the activations the backward-data network needs -> (logits, tape)."""
         pr = self._packed or self._prepare()
-        if not x.is_cuda:
-            raise AdmError("EncoderUNetModel.log_prob_grad: x must be a device tensor (no CPU fallback)")
         with torch.no_grad():
             x = x.detach().to(torch.float32).contiguous()
             tape = []
             logits = self._head_forward(pr, self._features(pr, x, timesteps, tape), tape)
+        return logits, tape
+
+    def _backward_tape(self, tape, dl):
+        """dl = d(loss)/d(logits) fp32 [N, 1000] -> d(loss)/dx fp32 [N,3,H,W] (data gradients only)."""
+        pr = self._packed
+        with torch.no_grad():
             g = None
             for kind, s, t in reversed(tape):
                 if kind == "pool":
                     hd = pr.head
                     n, hh, ww, c = t["h"].shape
-                    dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale)
                     da0 = ops.linear_f32(dl, hd["wc_t"], None)
                     dqkv = ops.pool_attn_bwd(t["qkv"], t["wts"], da0, t["t"], s.num_heads)
                     dtok = self._bwd_conv(pr, dqkv.view(n * t["tpad"] // 64, 8, 8, 3 * c), hd["wqkv_bwd"], c, 1)
@@ -132,4 +142,33 @@ class EncoderUNetModel(AdmNet):
                 elif kind == "stem":
                     d = pr.blocks[s.prefix]
                     g = ops.conv(g, d["w_bwd"], pr.zero_bias, s.cin, 9, out_f32_nchw=True)
-            return (g, logits) if return_logits else g
+            return g
+
+    def log_prob_grad(self, x, timesteps, y, scale: float = 1.0, return_logits: bool = False):
+        """scale * grad_x sum_n log_softmax(f(x,t))[n, y_n]; fp32 [N,3,H,W]."""
+        if not x.is_cuda:
+            raise AdmError("EncoderUNetModel.log_prob_grad: x must be a device tensor (no CPU fallback)")
+        logits, tape = self._forward_tape(x, timesteps)
+        with torch.no_grad():
+            dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale)
+        g = self._backward_tape(tape, dl)
+        return (g, logits) if return_logits else g
+
+
+class _ClassifierFn(torch.autograd.Function):
+    """torch.autograd bridge over the explicit backward network: forward = the HIP classifier with its tape kept,
+    backward(dlogits) = EncoderUNetModel._backward_tape.  Only d/dx exists (the engine is inference-only)."""
+
+    @staticmethod
+    def forward(ctx, x, timesteps, net):
+        logits, tape = net._forward_tape(x, timesteps)
+        ctx.net, ctx.tape, ctx.x_dtype = net, tape, x.dtype
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        tape, ctx.tape = ctx.tape, None  # one backward per forward, like a graph without retain_graph
+        if tape is None:
+            raise RuntimeError("the HIP classifier's activations were already released (backward called twice)")
+        g = ctx.net._backward_tape(tape, dlogits.detach().to(torch.float32).contiguous())
+        return g.to(ctx.x_dtype), None, None

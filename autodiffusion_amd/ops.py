@@ -40,6 +40,11 @@ def _ptr(t: Optional[torch.Tensor], dtype=None, name="tensor") -> Optional[int]:
         raise AdmError(f"{name}: must be contiguous")
     if dtype is not None and t.dtype != dtype:
         raise AdmError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch in the CURRENT device's context on its current stream (_stream): a pointer of another GPU
+        # there is a memory fault or a silent cross-device access
+        raise AdmError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                       "call torch.cuda.set_device(tensor.device) (dist_util.setup_dist does) before using the HIP path")
     return t.data_ptr()
 
 

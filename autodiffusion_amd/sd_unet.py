@@ -264,10 +264,14 @@ class UNetModel(HipModule):
         if context_key is None:
             return self._context_kv(pr, context, n), True
         ck = (context_key, tuple(context.shape))
-        if pr.kv_cache is None or pr.kv_cache[0] != ck:
-            pr.kv_cache = (ck, self._context_kv(pr, context, n))
-            return pr.kv_cache[1], True
-        return pr.kv_cache[1], False
+        sid = torch.cuda.current_stream(context.device).cuda_stream  # per launching stream: see forward()
+        if pr.kv_cache is None:
+            pr.kv_cache = {}
+        hit = pr.kv_cache.get(sid)
+        if hit is None or hit[0] != ck:
+            hit = pr.kv_cache[sid] = (ck, self._context_kv(pr, context, n))
+            return hit[1], True
+        return hit[1], False
 
     accepts_context_key = True
 
@@ -282,7 +286,13 @@ class UNetModel(HipModule):
             return self._forward(x, timesteps, kvs, context.shape[1], y)
         if not timesteps.is_cuda:
             raise AdmError("latent UNetModel (graph mode): timesteps must be a device tensor")
-        key = (tuple(x.shape), x.dtype, tuple(timesteps.shape), timesteps.dtype, tuple(context.shape))
+        # one captured graph (hipGraphExec + static input / output buffers + private allocator pool) per input shape AND
+        # per launching stream: the same entry replayed from two streams would put one exec in flight twice and race its
+        # static buffers (the memory fault recorded in round 1 when two half-batches were replayed concurrently).  With
+        # the stream in the key, evaluations on different streams own disjoint graphs and may overlap; replays on one
+        # stream serialise by stream order.
+        key = (tuple(x.shape), x.dtype, tuple(timesteps.shape), timesteps.dtype, tuple(context.shape),
+               torch.cuda.current_stream(x.device).cuda_stream)
         entry = pr.graphs.get(key)
         if entry is None:
             sx, st = x.clone(), timesteps.clone()

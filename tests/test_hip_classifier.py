@@ -169,3 +169,39 @@ def test_classifier_logits_and_guidance_gradient_golden(ops):
     assert rel(g2, 3.0 * grad) < 2.5e-2  # the scale enters at d logits; bf16 roundings differ elementwise
     # bitwise reproducible (no atomics anywhere in the backward network)
     assert torch.equal(m.log_prob_grad(x, t, y, 1.0), grad)
+
+
+def test_reference_cond_fn_closure_runs_unchanged_over_the_hip_classifier(ops):
+    """The closure of search_imagenet64_classifier_guidance.py:319-326 (restated: enable_grad island, ``classifier(x_in, t)``,
+    ``log_softmax``, ``autograd.grad(selected.sum(), x_in)[0] * scale``) over the HIP classifier: its torch.autograd node runs
+    the explicit backward-data network, so the result is that of ``log_prob_grad`` -- and the reference's fp32 golden."""
+    g = golden("classifier_c64")
+    m = _classifier()
+    x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))
+    classifier, classifier_scale = m, 2.0
+
+    def cond_fn(x, t, y=None):
+        assert y is not None
+        with torch.enable_grad():
+            x_in = x.detach().requires_grad_(True)
+            logits = classifier(x_in, t)
+            log_probs = F.log_softmax(logits, dim=-1)
+            selected = log_probs[range(len(logits)), y.view(-1)]
+            return torch.autograd.grad(selected.sum(), x_in)[0] * classifier_scale
+
+    with torch.no_grad():  # the sample loops call cond_fn under no_grad
+        got = cond_fn(x, t, y)
+    want = m.log_prob_grad(x, t, y, 1.0) * classifier_scale
+    assert got.shape == x.shape and got.dtype == torch.float32
+    r = rel(got, want)
+    print("cond_fn closure vs log_prob_grad rel", r, "bit-equal:", bool(torch.equal(got, want)))
+    assert r < 1e-3  # d logits comes from torch's log_softmax backward instead of adm_logsoftmax_grad: last-ulp differences
+    assert rel(got.cpu(), 2.0 * torch.from_numpy(g["grad"])) < 5e-2
+    # a second backward through the same node has nothing to differentiate (activations are released)
+    x_in = x.detach().requires_grad_(True)
+    with torch.enable_grad():
+        lg = m(x_in, t)
+    lg.sum().backward()
+    assert x_in.grad is not None and torch.isfinite(x_in.grad).all()
+    # without requires_grad the plain inference path is taken and no graph is recorded
+    assert not m(x, t).requires_grad

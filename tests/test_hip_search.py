@@ -127,53 +127,6 @@ def test_full_size_adm64_properties():
     assert not torch.equal(a, ev.sample_batch(5, seed=12))
 
 
-def test_full_size_adm64_and_classifier_match_the_oracle():
-    """BASELINE-size networks against the golden-pinned CPU oracle on the same weights and inputs (fan-in scaled
-    random weights: no checkpoint is reachable offline): the 296 M-parameter ADM-64 UNet's eps/variance output and
-    the 65 M-parameter classifier's guidance gradient.  Tolerances as for the small golden models (bf16 torso vs
-    fp32): relative Frobenius error <= 2e-2 (UNet) / 5e-2 (gradient through ~40 bf16 layers)."""
-    import os
-    import sys
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    if os.environ.get("ADM_SLOW_TESTS") != "1":
-        # the CPU oracle needs ~6.5 minutes for these two evaluations on a one-GPU box's host share; last run
-        # (MI355X, round 1): UNet 0.98e-2, classifier gradient 1.95e-2 relative Frobenius error
-        pytest.skip("set ADM_SLOW_TESTS=1 to run the full-size oracle comparison (minutes of CPU time)")
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import adm64_flags
-    from autodiffusion_amd.script_util import classifier_defaults, create_classifier, create_model_and_diffusion
-    from oracle import nets
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
-    model, _ = create_model_and_diffusion(**adm64_flags(class_cond=True, dynamic=False))
-    model.to(DEV).randomize_(7)
-    g = torch.Generator().manual_seed(21)
-    x = torch.randn(1, 3, 64, 64, generator=g)
-    t = torch.tensor([424])
-    y = torch.tensor([207])
-    got = model(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
-    P = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    with torch.no_grad():
-        ref = nets.unet_forward(P, model.plan, x, t, y)
-    r = ((got - ref).norm() / ref.norm()).item()
-    print("full-size ADM-64 rel", r)
-    assert torch.isfinite(got).all() and r < 2e-2, r
-    del model, P
-    cf = classifier_defaults()
-    cf.update(image_size=64, classifier_depth=4)
-    clf = create_classifier(**cf)
-    clf.to(DEV).randomize_(11)
-    x2 = torch.randn(2, 3, 64, 64, generator=g)
-    t2 = torch.tensor([926, 153])
-    y2 = torch.tensor([5, 999])
-    grad = clf.log_prob_grad(x2.to(DEV), t2.to(DEV), y2.to(DEV), 1.0).float().cpu()
-    Pc = {k: v.detach().float().cpu() for k, v in clf.state_dict().items()}
-    refg = nets.classifier_grad(Pc, clf.plan, x2, t2, y2, 1.0)
-    r = ((grad - refg).norm() / refg.norm()).item()
-    print("full-size classifier gradient rel", r)
-    assert torch.isfinite(grad).all() and r < 5e-2, r
-
-
 @pytest.mark.parametrize("name", ["adm128", "lsun256"])
 def test_full_size_other_reference_configs(name):
     """The other architectures SURVEY 8(d) lists -- ADM-G ImageNet-128 (`GD/configs/128_guided_sample.sh:1`: 256
