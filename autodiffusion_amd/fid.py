@@ -104,12 +104,12 @@ class ActivationAccumulator:
                                      self.dim, torch.cuda.current_stream().cuda_stream), "adm_fid_accumulate")
         self.n += int(acts.shape[0])
 
-    def pooled(self, group=None):
-        """(n, s1, s2) summed over ranks: ONE all_gather per candidate of one packed float64 buffer
+    def pooled(self, group=None, local=False):
+        """(n, s1, s2) summed over ranks (local=True: this rank's sums only -- population-parallel mode): ONE all_gather per candidate of one packed float64 buffer
         [n | s1 (dim) | s2 (dim^2)] (8 B + 16 KiB + 32 MiB per rank at dim 2048), summed in rank order (deterministic).
         n rides in the buffer (exact in float64), so no per-rank host synchronisation is needed."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if local or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return self.n, self.s1, self.s2
         world = dist.get_world_size(group)
         d = self.dim
@@ -125,8 +125,8 @@ class ActivationAccumulator:
         n = int(round(float(tot[0].item())))
         return n, tot[1:1 + d].contiguous(), tot[1 + d:].reshape(d, d).contiguous()
 
-    def statistics(self, group=None) -> FIDStatistics:
-        n, s1, s2 = self.pooled(group)
+    def statistics(self, group=None, local=False) -> FIDStatistics:
+        n, s1, s2 = self.pooled(group, local)
         if n < 2:
             raise ValueError("need at least 2 activations for a covariance")
         s1 = s1.cpu().numpy()
@@ -136,9 +136,9 @@ class ActivationAccumulator:
         return FIDStatistics(mu, sigma)
 
 
-    def frechet_distance_device(self, ref: FIDStatistics, group=None) -> float:
+    def frechet_distance_device(self, ref: FIDStatistics, group=None, local=False) -> float:
         """FID against host reference statistics without the activations' sums leaving the device."""
-        n, s1, s2 = self.pooled(group)
+        n, s1, s2 = self.pooled(group, local)
         if n < 2:
             raise ValueError("need at least 2 activations for a covariance")
         mu = s1 / n

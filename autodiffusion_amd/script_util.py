@@ -80,6 +80,9 @@ def create_model(image_size, num_channels, num_res_blocks, channel_mult="", lear
         use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown,
         use_new_attention_order=use_new_attention_order, dynamic=use_dynamic_unet)
     # dropout / use_checkpoint only matter for training; accepted and ignored at inference
+    if not use_fp16:
+        from .unet import warn_compute_dtype
+        warn_compute_dtype("create_model", "use_fp16")
     return UNetModel(plan, use_fp16=use_fp16)
 
 
@@ -138,6 +141,9 @@ def create_classifier(image_size, classifier_use_fp16, classifier_width, classif
         channel_mult=_default_channel_mult(image_size), num_head_channels=64,
         use_scale_shift_norm=classifier_use_scale_shift_norm, resblock_updown=classifier_resblock_updown,
         encoder_only=True, pool=classifier_pool)
+    if not classifier_use_fp16:  # the reference's default: every classifier runs fp32 (script_util.py:33)
+        from .unet import warn_compute_dtype
+        warn_compute_dtype("create_classifier", "classifier_use_fp16")
     return EncoderUNetModel(plan, use_fp16=classifier_use_fp16)
 
 

@@ -30,12 +30,6 @@ from .evaluate import CandidateEvaluator
 from .fid import ActivationAccumulator, FIDStatistics, cal_fid
 from .schedule import space_timesteps
 
-def _local_stats(acc):
-    n, s1, s2 = acc.n, acc.s1.cpu().numpy(), acc.s2.cpu().numpy()
-    mu = s1 / n
-    return mu, (s2 - n * np.outer(mu, mu)) / (n - 1)
-
-
 choice = lambda x: x[np.random.randint(len(x))] if isinstance(x, tuple) else choice(tuple(x))  # noqa: E731
 
 
@@ -99,28 +93,19 @@ class EvolutionSearcher(object):
 
     def get_cand_fid(self, cand=None, args=None):
         if self.population_parallel:
-            return self._cand_fid_local(cand, args)
-        return self._cand_fid_sharded(cand, args)
+            # whole candidate on this rank alone: its batches are seeded as a single-rank run would seed them, the
+            # statistics stay local and there is no collective inside (ranks evaluate different candidates)
+            return self._cand_fid(cand, args, world=1, rank=0, local=True)
+        return self._cand_fid(cand, args, world=dist_util.get_world_size(), rank=dist_util.get_rank(), local=False)
 
-    def _cand_fid_local(self, cand, args):
-        """Whole candidate on this rank alone (population-parallel mode): no collective inside."""
-        import torch.distributed as dist
-        was = dist.is_available() and dist.is_initialized()
-        saved = (dist_util.get_world_size, dist_util.get_rank)
-        dist_util.get_world_size, dist_util.get_rank = (lambda: 1), (lambda: 0)
-        try:
-            return self._cand_fid_sharded(cand, args, allow_barrier=not was)
-        finally:
-            dist_util.get_world_size, dist_util.get_rank = saved
-
-    def _cand_fid_sharded(self, cand=None, args=None, allow_barrier=True):
+    def _cand_fid(self, cand, args, *, world, rank, local):
+        """`world` / `rank` = how this candidate's image batches are sharded (1 / 0: all of them here)."""
         args = args if args is not None else self.args
         t1 = time.time()
         self._ev.set_candidate(cand)
         reset_time = time.time() - t1
         t1 = time.time()
         logger.log("sampling...")
-        world, rank = dist_util.get_world_size(), dist_util.get_rank()
         seed0 = (int(getattr(args, "seed", 0)) * 1000003 + zlib.crc32(str(cand).encode())) & 0x7FFFFFFF
         acc = ActivationAccumulator(self.feature_dim, self._ev.device) if self.features is not None else None
         host_images = []
@@ -139,22 +124,17 @@ class EvolutionSearcher(object):
             produced += args.batch_size * world
             batch_idx += 1
             logger.log('created ' + str(min(produced, batch_idx * args.batch_size * world)) + ' samples')
-        if world > 1 and allow_barrier:
+        if world > 1:
             import torch.distributed as dist
             dist.barrier()
         logger.log("sampling complete")
         sample_time = time.time() - t1
         t1 = time.time()
         if acc is not None:
-            grp = None
-            if getattr(args, "fid_on_device", False) and not (world == 1 and self.population_parallel):
-                fid = acc.frechet_distance_device(self.ref_stats, grp)  # eigh on the GPU instead of the host sqrtm
+            if getattr(args, "fid_on_device", False):
+                fid = acc.frechet_distance_device(self.ref_stats, None, local=local)  # eigh on the GPU instead of the host sqrtm
             else:
-                if world == 1 and self.population_parallel:
-                    st = FIDStatistics(*_local_stats(acc))
-                else:
-                    st = acc.statistics(grp)
-                fid = float(st.frechet_distance(self.ref_stats))
+                fid = float(acc.statistics(None, local=local).frechet_distance(self.ref_stats))
         else:
             if world > 1:
                 raise NotImplementedError("host-evaluator FID with several ranks: pass a device `features` function "
@@ -197,8 +177,29 @@ class EvolutionSearcher(object):
         info['visited'] = True
         return True
 
+    def candidate_cost(self, cand) -> int:
+        """Relative cost of evaluating a candidate = UNet layer evaluations per image: every step costs `layer_num`
+        minus its skipped layers (a plain timestep list: one unit per step)."""
+        if isinstance(cand, dict):
+            L = int(getattr(self.model, "layer_num", 0) or getattr(self.args, "layer_num", 0) or 1)
+            return sum(max(1, L - len(sk)) for sk in cand["skip_layers"])
+        return len(cand)
+
+    @staticmethod
+    def assign_candidates(costs, world):
+        """Longest-processing-time-first: candidates sorted by cost (descending, ties by index) go one by one to the
+        least-loaded rank (ties: lowest rank).  Deterministic, so every rank derives the same owner list with no
+        communication; layer-skip candidates are cheaper, and round-robin left ranks finishing unevenly."""
+        owner = [0] * len(costs)
+        load = [0] * world
+        for i in sorted(range(len(costs)), key=lambda j: (-costs[j], j)):
+            r = min(range(world), key=lambda q: (load[q], q))
+            owner[i] = r
+            load[r] += costs[i]
+        return owner
+
     def flush_pending(self):
-        """Evaluate every queued candidate: rank r takes candidates r, r+W, ...; one all_gather of the FIDs."""
+        """Evaluate every queued candidate, each on ONE rank (cost-aware assignment); one all_gather of the FIDs."""
         if not self._pending:
             return
         import torch.distributed as dist
@@ -206,16 +207,19 @@ class EvolutionSearcher(object):
         world = dist.get_world_size() if multi else 1
         rank = dist.get_rank() if multi else 0
         pending, self._pending = self._pending, []
-        fids = np.full(len(pending), np.nan, dtype=np.float64)
-        for i in range(rank, len(pending), world):
-            fids[i] = self.get_cand_fid(args=self.args, cand=eval(pending[i]))
+        cands = [eval(c) for c in pending]
+        owner = self.assign_candidates([self.candidate_cost(c) for c in cands], world)
+        fids = np.zeros(len(pending), dtype=np.float64)
+        for i, c in enumerate(cands):
+            if owner[i] == rank:
+                fids[i] = self.get_cand_fid(args=self.args, cand=c)
         if multi:
             dev = self._ev.device if (self._ev is not None and dist.get_backend() == "nccl") else torch.device("cpu")
-            mine = torch.from_numpy(np.nan_to_num(fids, nan=0.0)).to(dev)
+            mine = torch.from_numpy(fids).to(dev)
             parts = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
             for i in range(len(pending)):
-                fids[i] = float(parts[i % world][i])
+                fids[i] = float(parts[owner[i]][i])
         for cand, fid in zip(pending, fids):
             self.vis_dict[cand]['fid'] = float(fid)
             logger.log('cand: {}, fid: {}'.format(cand, float(fid)))

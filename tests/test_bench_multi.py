@@ -1,0 +1,37 @@
+"""GPU: bench.py's N > 1 path rehearsed as the driver launches it -- `python -m torch.distributed.run --nproc-per-node 2
+bench.py --gpus 2 ...` in FRESH child processes -- with two ranks sharing the one GPU of the test box (`--dist-backend
+gloo`: the collectives of the timing protocol run on the CPU; on a real node the backend is nccl = RCCL).  Checks the
+JSON contract: one line from rank 0, n_gpus / global_batch / weak scaling, MAX-over-ranks timing consistent with `value`."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("workload", ["guided", "sd"])
+def test_bench_two_ranks_prints_one_consistent_json_line(workload):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    batch = 8 if workload == "guided" else 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--batch", str(batch), "--workload", workload, "--no-cpu-baseline", "--no-kernel-events"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * batch and out["higher_is_better"] is True and out["vs_baseline"] is None
+    assert out["dtype"] == "bf16" and "synthetic" in out["data"] and out["value"] > 0
+    # value = units all ranks processed / the (max-over-ranks) time of the K timed steps
+    assert abs(out["value"] - 2 * batch / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]

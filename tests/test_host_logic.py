@@ -114,3 +114,35 @@ def test_argparse_helpers():
     assert str2bool("Yes") is True and str2bool(False) is False
     with pytest.raises(argparse.ArgumentTypeError):
         str2bool("maybe")
+
+
+def test_asking_for_the_fp32_network_warns_loudly(monkeypatch):
+    """`use_fp16=False` (ADM-G-128, configs/128_guided_sample.sh:1) and `classifier_use_fp16=False` (the default of every
+    reference classifier, script_util.py:33) cannot be honoured -- the HIP path computes in bf16 with fp32 accumulation --
+    so the factories say so once, on the log and as a Python warning, instead of silently handing back a bf16 model."""
+    import warnings
+    from autodiffusion_amd import logger, unet
+    from autodiffusion_amd.script_util import (classifier_defaults, create_classifier, create_model_and_diffusion,
+                                               model_and_diffusion_defaults)
+    lines = []
+    monkeypatch.setattr(logger, "log", lambda *a: lines.append(" ".join(map(str, a))))
+    monkeypatch.setattr(unet, "_warned_precision", set())
+    d = model_and_diffusion_defaults()
+    d.update(image_size=32, num_channels=32, num_res_blocks=1, channel_mult="1,2", attention_resolutions="16",
+             num_head_channels=32, resblock_updown=True, use_scale_shift_norm=True, use_fp16=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m, _ = create_model_and_diffusion(**d)
+        create_model_and_diffusion(**d)  # once per process and flag
+        cf = classifier_defaults()
+        cf.update(classifier_width=64, classifier_depth=1)
+        c = create_classifier(**cf)
+    assert m.dtype == torch.float32 and m.compute_dtype == torch.bfloat16 and c.compute_dtype == torch.bfloat16
+    msgs = [str(x.message) for x in w]
+    assert len(msgs) == 2 and "use_fp16=False" in msgs[0] and "classifier_use_fp16=False" in msgs[1]
+    assert len(lines) == 2 and all(ln.startswith("WARNING: ") and "bf16" in ln for ln in lines)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        d["use_fp16"] = True
+        create_model_and_diffusion(**d)
+    assert not w

@@ -34,8 +34,8 @@ def test_nothing_reads_the_reference_at_run_time():
     for f in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(ROOT, f)).read()
     for path in _py_files("tests"):
-        if path.endswith("capture_golden.py") or path.endswith("capture_ea_dynamic.py") or path.endswith("capture_sd.py") or path.endswith("capture_sd_samplers.py") or path.endswith("test_layout.py"):
-            continue
+        if os.path.basename(path).startswith("capture_") or path.endswith("test_layout.py"):
+            continue  # the capture scripts run in the build container only; their outputs are the committed .npz
         assert "/root/reference" not in open(path).read(), path
 
 

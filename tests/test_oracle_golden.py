@@ -213,3 +213,30 @@ def test_unconditional_uniform_ddim4_loops():
     for name, ddim in (("ddim", True), ("ddpm", False)):
         s = sampler.sample_loop(d, fn, T(g["x_T"]), use_ddim=ddim, noises=noises)
         np.testing.assert_allclose(s.numpy(), g[f"{name}_sample"], rtol=2e-3, atol=1e-3)
+
+
+def test_oracle_at_baseline_size_matches_the_reference_captures():
+    """The oracle pinned at BASELINE size too: the 295.9 M-parameter ADM-G-64 UNet and the depth-4 64x64 classifier's
+    guidance gradient against outputs of the reference's own modules (tests/golden/capture_fullsize.py)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import adm64_flags
+    from autodiffusion_amd.script_util import (classifier_defaults, create_classifier, create_model_and_diffusion)
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    g = golden("full_adm64")
+    plan = create_model_and_diffusion(**adm64_flags(class_cond=True, dynamic=False))[0].plan
+    P = nets.params_from_numpy(filled(plan))
+    with torch.no_grad():
+        out = nets.unet_forward(P, plan, T(g["x"][:1]), T(g["t"][:1]), T(g["y"][:1]))
+    r = float((out - T(g["out"][:1])).norm() / T(g["out"][:1]).norm())
+    assert r < 1e-4, r
+    del P
+    gc = golden("full_clf64")
+    cf = classifier_defaults()
+    cf.update(image_size=64, classifier_depth=4)
+    cplan = create_classifier(**cf).plan
+    Pc = nets.params_from_numpy(filled(cplan))
+    grad = nets.classifier_grad(Pc, cplan, T(gc["x"]), T(gc["t"]), T(gc["y"]), 1.0)
+    r = float((grad - T(gc["grad"])).norm() / T(gc["grad"]).norm())
+    assert r < 1e-3, r

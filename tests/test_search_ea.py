@@ -178,3 +178,59 @@ def test_dynamic_candidates_respect_the_index_budget(monkeypatch):
         assert used <= s.max_index_number and all(len(set(sk)) == len(sk) and all(0 <= l < 14 for l in sk) for sk in c["skip_layers"])
         gen = s.cand2gen(c)
         assert len(gen) == s.max_index_number
+
+
+def test_cost_aware_assignment_balances_layer_skip_candidates():
+    """Round-robin `i % world` left ranks finishing unevenly (layer-skip candidates are cheaper).  The
+    longest-first greedy assignment is deterministic and bounds the imbalance by one candidate's cost."""
+    assign = search.EvolutionSearcher.assign_candidates
+    assert assign([4] * 8, 4) == [0, 1, 2, 3, 0, 1, 2, 3]            # equal costs: the old layout
+    costs = [58 * 4, 30 * 4, 58 * 4, 20 * 4, 25 * 4, 58 * 4, 40 * 4, 58 * 4, 22 * 4, 35 * 4]
+    for world in (2, 4, 8):
+        owner = assign(costs, world)
+        assert owner == assign(list(costs), world) and set(owner) <= set(range(world))
+        load = [sum(c for c, o in zip(costs, owner) if o == r) for r in range(world)]
+        rr = [sum(c for i, c in enumerate(costs) if i % world == r) for r in range(world)]
+        assert max(load) - min(load) <= max(costs) and max(load) <= max(rr)
+    s, _, _ = _dyn_searcher(1, False, 14)
+    assert s.candidate_cost({"timesteps": [1, 2, 3], "skip_layers": [[], [0, 1], list(range(14))]}) == 14 + 12 + 1
+    assert search.EvolutionSearcher.candidate_cost(s, [5, 6, 7, 8]) == 4
+
+
+def _pp_dyn_rank(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    logger.log = lambda *a: None
+    s, evaluated, _ = _dyn_searcher(7, True, 14, population_parallel=True)
+    random.seed(0)
+    np.random.seed(0)
+    s.search()
+    cost = sum(s.candidate_cost(eval(c)) for c in evaluated)
+    np.savez(out + f".{rank}.npz", n=len(evaluated), cost=cost, top=np.array(s.keep_top_k[50]),
+             fid=np.array([s.vis_dict[c]["fid"] for c in s.keep_top_k[50]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dynamic_population_parallel_two_ranks_gloo(tmp_path, monkeypatch):
+    """Joint timestep + layer-skip search with whole candidates sharded over two ranks by cost: both ranks end with the
+    single-process result, no candidate is evaluated twice, and the two ranks' summed costs are close."""
+    import socket
+    import torch.multiprocessing as mp
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    s, evaluated, _ = _dyn_searcher(7, True, 14)
+    random.seed(0)
+    np.random.seed(0)
+    s.search()
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    out = str(tmp_path / "ppd")
+    mp.spawn(_pp_dyn_rank, args=(2, port, out), nprocs=2, join=True)
+    z0, z1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert int(z0["n"]) + int(z1["n"]) == len(evaluated)
+    total = int(z0["cost"]) + int(z1["cost"])
+    assert abs(int(z0["cost"]) - int(z1["cost"])) <= 0.1 * total
+    for z in (z0, z1):
+        assert z["top"].tolist() == s.keep_top_k[50]
+        np.testing.assert_array_equal(z["fid"], [s.vis_dict[c]["fid"] for c in s.keep_top_k[50]])
