@@ -1060,7 +1060,11 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   const long long tiles = (long long)m_tiles * kk.nblocks_n;
   ADM_REQUIRE(tiles < (1ll << 31), ADM_E_SHAPE, "adm_conv: too many tiles");
   kk.total_tiles = (int)tiles;
-  const unsigned blocks = (unsigned)(tiles < slots ? tiles : slots);
+  unsigned blocks = (unsigned)(tiles < slots ? tiles : slots);
+#ifdef ADM_CONV_TIMING
+  // diagnostic build only: cap the persistent grid (how long is a tile's epilogue when few CUs share the HBM?)
+  if (const char* e = getenv("ADM_CONV_MAX_BLOCKS")) { const unsigned cap = (unsigned)atoi(e); if (cap > 0 && cap < blocks) blocks = cap; }
+#endif
   hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS>), dim3(blocks), dim3(NT), smem, s, kk);
   return adm_check_launch("adm_conv");
 }

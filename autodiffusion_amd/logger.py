@@ -44,3 +44,12 @@ def log(*args):
     if _file is not None:
         _file.write(line + "\n")
         _file.flush()
+
+
+def warn(*args):
+    """Like log(), but to stderr (stdout may be a machine-read channel: bench.py prints ONE JSON line there)."""
+    line = " ".join(str(a) for a in args)
+    print(line, file=sys.stderr, flush=True)
+    if _file is not None:
+        _file.write(line + "\n")
+        _file.flush()

@@ -48,7 +48,7 @@ def warn_compute_dtype(what: str, flag: str):
     msg = (f"{what}: {flag}=False asks for the reference's fp32 network; the MI355X HIP path computes in bf16 with fp32 "
            "accumulation, GroupNorm statistics, softmax and embeddings (one evaluation differs from the reference's fp32 "
            "result by ~1e-2 relative, tests/test_hip_fullsize.py; its own fp16 torso differs by 1.4e-3)")
-    logger.log("WARNING: " + msg)
+    logger.warn("WARNING: " + msg)
     warnings.warn(msg, stacklevel=3)
 
 

@@ -125,7 +125,7 @@ def test_asking_for_the_fp32_network_warns_loudly(monkeypatch):
     from autodiffusion_amd.script_util import (classifier_defaults, create_classifier, create_model_and_diffusion,
                                                model_and_diffusion_defaults)
     lines = []
-    monkeypatch.setattr(logger, "log", lambda *a: lines.append(" ".join(map(str, a))))
+    monkeypatch.setattr(logger, "warn", lambda *a: lines.append(" ".join(map(str, a))))
     monkeypatch.setattr(unet, "_warned_precision", set())
     d = model_and_diffusion_defaults()
     d.update(image_size=32, num_channels=32, num_res_blocks=1, channel_mult="1,2", attention_resolutions="16",
