@@ -286,8 +286,11 @@ attn_kernel_v1(const AttnK p) {
 // launch bounds: >= 2 waves per SIMD for every width caps the kernel at 256 registers, so hipcc keeps the MFMA accumulators in
 // VGPRs (with no bound it parks them in AGPRs and copies them out with v_accvgpr_read: slower, and the 80-wide
 // instantiation then returned wrong scores for one query tile); 3 waves (168 registers) up to 64-wide heads
+#ifndef ADM_ATTN_WAVES
+#define ADM_ATTN_WAVES 3
+#endif
 template <int D>
-__global__ void __launch_bounds__(256, D <= 64 ? 3 : 2)
+__global__ void __launch_bounds__(256, D <= 64 ? ADM_ATTN_WAVES : 2)
 attn_kernel(const AttnK p) {
   constexpr int KS = D / 32;   // 32-deep k-steps of QK^T
   constexpr bool R16 = (D % 32) == 16;  // plus one 16-deep step (v_mfma_f32_16x16x16_bf16): head widths 48, 80, 112
@@ -296,7 +299,14 @@ attn_kernel(const AttnK p) {
   constexpr float MOVE_THR = 8.0f;  // log2 units: the running max follows once some (s - m) * scale_log2 exceeds it
   // LDS row pitch = 8 mod 16 dwords (conflict-free for the b128 fragment reads and the transposing reads): 48- and
   // 80-wide heads have it unpadded (24 / 40 dwords), the multiples of 32 need the 16-element pad
-  constexpr int KROW = D + (((D / 2) % 16 == 8) ? 0 : PADE);
+  // 64-wide heads (every ADM / classifier attention of the benchmarked path): K and V tiles go global -> LDS by LDS-DMA
+  // (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write, 16 registers fewer).  A DMA piece is lane-linear
+  // (1 KB = 8 rows of 128 B), so the rows are unpadded and the bank spread comes from an XOR swizzle instead: the
+  // 16-byte segment s of row r is stored in slot s ^ (r & 7) -- applied on the GLOBAL side of the DMA (each lane fetches
+  // the segment that belongs in its slot) and on the LDS side of every fragment read; conflict-free for the
+  // ds_read_b128 K fragments and for the ds_read_b64_tr_b16 V^T reads.
+  constexpr bool DMA = D == 64;
+  constexpr int KROW = DMA ? D : D + (((D / 2) % 16 == 8) ? 0 : PADE);
   // K and V tiles row-major, double-buffered: the next tile's global loads fly during this tile's MFMAs
   __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KT * KROW];
   __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KT * KROW];
@@ -352,10 +362,44 @@ attn_kernel(const AttnK p) {
   const int ntiles = (p.Tk + KT - 1) / KT;
   ATT_T0();
   AdmTileRegs<KT, D, 256> kr, vr;
-  kr.load_buf(rsk, p.Ckv, kcol, 0, tid);
-  vr.load_buf(rsk, p.Ckv, vcol, 0, tid);
-  kr.store(Ks[0], KROW, tid);
-  vr.store(Vs[0], KROW, tid);
+  // LDS-DMA of key tile kt0 into ring slot kt0 & 1: each wave moves pieces 2w, 2w + 1 of K and of V (hand-written: hipcc
+  // orders EVERY later LDS access behind a pending LDS-DMA builtin, i.e. it would wait for the next tile's data before
+  // reading this tile's fragments; an asm statement is invisible to that pass, so the loop counts the DMA itself --
+  // s_waitcnt vmcnt(0) + barrier at the bottom of the tile that issued it; no other vector-memory operation is in flight
+  // inside the loop)
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4s;
+  const unsigned long long kvbase = (unsigned long long)(p.kv + (long long)n * p.kv_rows * p.Ckv);
+  const u32x4s rsk_s = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kvbase),
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kvbase >> 32)) & 0xffffu,
+                        (unsigned)__builtin_amdgcn_readfirstlane(p.Tk * p.Ckv * 2), 0x00020000u};
+  const unsigned lds_k = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&Ks[0][0];
+  const unsigned lds_v = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)&Vs[0][0];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_tile = [&](int kt0) {
+    const unsigned slot = (unsigned)(kt0 & 1) * (KT * KROW * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = wave_u * 2 + j;
+      const int row = kt0 * KT + piece * 8 + (lane >> 3);
+      const int gseg = (lane & 7) ^ (lane >> 3);
+      const unsigned voff_k = (unsigned)(row * p.Ckv + kcol + gseg * 8) * 2u, voff_v = (unsigned)(row * p.Ckv + vcol + gseg * 8) * 2u;
+      const unsigned dst_k = lds_k + slot + piece * 1024, dst_v = lds_v + slot + piece * 1024;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff_k), "s"(rsk_s), "s"(dst_k) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(voff_v), "s"(rsk_s), "s"(dst_v) : "memory");
+    }
+  };
+  if constexpr (DMA) {
+    dma_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    kr.load_buf(rsk, p.Ckv, kcol, 0, tid);
+    vr.load_buf(rsk, p.Ckv, vcol, 0, tid);
+    kr.store(Ks[0], KROW, tid);
+    vr.store(Vs[0], KROW, tid);
+  }
   __syncthreads();
 
   // S - m of key tile `kt0` (its K is in ring slot kt0 & 1): 4 key tiles x 2 query tiles; scheduling fences pin the
@@ -376,7 +420,8 @@ attn_kernel(const AttnK p) {
 #if ADM_ATTN_ABL == 5
         kfr[slot][ks] = qf[0][ks];
 #else
-        kfr[slot][ks] = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+        kfr[slot][ks] = *reinterpret_cast<const bf16x8*>(
+            &Kc[(kt * 16 + lc) * KROW + (DMA ? ((ks * 4 + lq) ^ (lc & 7)) * 8 : ks * 32 + lq * 8)]);
 #endif
       if constexpr (R16) kfr16[slot] = *reinterpret_cast<const adm_s16x4*>(&Kc[(kt * 16 + lc) * KROW + KS * 32 + lq * 4]);
     };
@@ -418,8 +463,12 @@ attn_kernel(const AttnK p) {
     const bool next = kt0 + 1 < ntiles;
 #endif
     if (next) {
-      kr.load_buf(rsk, p.Ckv, kcol, k0 + KT, tid);
-      vr.load_buf(rsk, p.Ckv, vcol, k0 + KT, tid);
+      if constexpr (DMA) {
+        dma_tile(kt0 + 1);
+      } else {
+        kr.load_buf(rsk, p.Ckv, kcol, k0 + KT, tid);
+        vr.load_buf(rsk, p.Ckv, vcol, k0 + KT, tid);
+      }
     }
     ATT_T(0);
     f32x4 st[4][2];
@@ -436,7 +485,7 @@ attn_kernel(const AttnK p) {
 #if ADM_ATTN_ABL == 4
         vfr[slot][kb] = qf[kb][0];
 #else
-        vfr[slot][kb] = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
+        vfr[slot][kb] = DMA ? adm_tr_frag_swz(Vc, kb * 32, dt * 16, lc, lq) : adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
 #endif
     };
 #ifdef ADM_ATTN_NOROLLV
@@ -538,7 +587,9 @@ attn_kernel(const AttnK p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     ATT_T(5);
-    if (next) {
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed
+    } else if (next) {
       kr.store(Ks[(kt0 + 1) & 1], KROW, tid);
       vr.store(Vs[(kt0 + 1) & 1], KROW, tid);
     }
