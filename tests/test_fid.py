@@ -160,3 +160,22 @@ def test_gpu_frechet_distance_matches_host_sqrtm_at_inception_width():
     t_host = time.time() - t0
     print(f"FID {got:.6f} (device, {t_dev:.2f} s) vs {want:.6f} (host sqrtm, {t_host:.2f} s)")
     assert abs(got - want) <= 1e-6 * abs(want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d", [(37, 100), (5, 64), (300, 196), (1, 2048)])
+def test_gram_kernel_ragged_shapes_and_symmetry(n, d):
+    """The f64-MFMA Gram kernel computes the upper triangle of tiles and mirrors it: ragged sample counts / widths that are
+    not multiples of the 64-wide tile or the 16-sample stage, against numpy float64, accumulated over two calls."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    g = torch.Generator().manual_seed(n * 1000 + d)
+    a1, a2 = torch.randn(n, d, generator=g) * 1.3 - 0.4, torch.randn(n + 3, d, generator=g)
+    acc = ActivationAccumulator(d, "cuda:0")
+    acc.add(a1.to("cuda:0"))
+    acc.add(a2.to("cuda:0"))
+    a = np.concatenate([a1.numpy(), a2.numpy()]).astype(np.float64)
+    s2 = acc.s2.cpu().numpy()
+    assert acc.n == 2 * n + 3 and np.array_equal(s2, s2.T)          # mirrored tiles are bit-identical
+    np.testing.assert_allclose(s2, a.T @ a, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(acc.s1.cpu().numpy(), a.sum(0), rtol=1e-12, atol=1e-12)

@@ -7,7 +7,8 @@ Stated tolerances (bf16 operands, fp32 accumulate / GroupNorm / softmax, vs the 
   one UNet evaluation              relative Frobenius error <= 2e-2   (the reference's own fp16 torso: 1.4e-3, see below)
   classifier logits                <= 2e-2 of max |logit|
   guidance gradient                <= 5e-2 relative Frobenius (backward through ~40 bf16 layers)
-  K-step guided loop, fp32 sample  <= 4e-2 relative Frobenius; uint8 image: >= 99 % of pixels within 8/255, >= 90 % within 2/255
+  K-step guided loop, fp32 sample  <= 2.5e-2 relative Frobenius (measured 1.1e-2 / 1.4e-2); uint8 image: >= 99 % of pixels
+                                   within 8/255, >= 90 % within 2/255 (measured 99.3 % / 95.5 %)
 `full_adm64.npz` also carries the reference's own mixed-precision (fp16 torso) output on the same input: the test
 prints our error next to the error the reference itself accepts (DESIGN.md section 4 quotes both).
 """
@@ -104,7 +105,23 @@ def test_adm64_unet_classifier_and_guided_loop_match_the_reference():
         rs = rel(sample, gl[f"ddim_{tag}_sample"])
         h = u8_hist(u8, gl[f"ddim_{tag}_uint8"])
         print(f"full ADM-G-64 4-step DDIM loop ({'guided' if tag == 'g' else 'unguided'}): sample rel {rs:.3e}, uint8 within k levels {h}")
-        assert rs < 4e-2 and h[8] >= 0.99 and h[2] >= 0.90, (tag, rs, h)
+        assert rs < 2.5e-2 and h[8] >= 0.99 and h[2] >= 0.90, (tag, rs, h)
+    # how much of the guided loop's error is the bf16 guidance gradient?  The same HIP loop with the gradient of the fp32
+    # CPU oracle (golden-pinned at this size, tests/test_oracle_golden.py) injected as cond_fn
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    from oracle import nets
+    Pc = nets.params_from_numpy(filled(c64.plan))
+    ev = CandidateEvaluator(model, diffusion, c64, image_size=64, use_ddim=True, device=DEV)
+    ev.set_candidate(gl["cand"].tolist())
+    ev.active_diffusion.overlap_guidance = False
+
+    def oracle_cond_fn(x, t, y=None, **kw):
+        return nets.classifier_grad(Pc, c64.plan, x.float().cpu(), t.cpu(), y.cpu(), 1.0).to(DEV)
+    sample = ev.active_diffusion.ddim_sample_loop(ev._model_fn, tuple(x_T.shape), noise=x_T.to(DEV), clip_denoised=True,
+                                                  model_kwargs={"y": yl.to(DEV)}, cond_fn=oracle_cond_fn, device=torch.device(DEV))
+    ri = rel(sample, gl["ddim_g_sample"])
+    print(f"full ADM-G-64 guided loop with the fp32 oracle gradient injected: sample rel {ri:.3e} (bf16 gradient: see above)")
+    assert ri < 2.5e-2, ri
 
 
 def test_adm128_unet_classifier_and_guided_10_step_loop_match_the_reference():
@@ -133,7 +150,7 @@ def test_adm128_unet_classifier_and_guided_10_step_loop_match_the_reference():
     rs = rel(sample, g["loop_sample"])
     h = u8_hist(u8, g["loop_uint8"])
     print(f"full ADM-G-128 guided 10-step DDIM loop: sample rel {rs:.3e}, uint8 within k levels {h}")
-    assert rs < 4e-2 and h[8] >= 0.99 and h[2] >= 0.90, (rs, h)
+    assert rs < 2.5e-2 and h[8] >= 0.99 and h[2] >= 0.90, (rs, h)
 
 
 def test_lsun256_dynamic_unet_matches_the_reference():

@@ -3,10 +3,15 @@ create_model_and_diffusion / create_classifier -> reset_diffusion(cand) -> ddim 
 (with classifier guidance and per-step layer skipping) -> uint8 NHWC batch, against the golden
 vectors captured from the reference (tests/golden/sampler_loops_*.npz) and the CPU oracle.
 
-Tolerance: 4 sampler steps through two bf16 networks with random fill-rule weights (a chaotic
-map: a random-weight UNet amplifies perturbations step to step).  Required: relative Frobenius
-error of the final fp32 sample <= 4e-2 (measured 1.4e-2) vs the reference's fp32 result and >= 97 % of uint8 pixels
-within 8 levels; the kernel-level tests carry the tight bounds.
+Tolerance (stated, and held to what is measured): 4 sampler steps through two bf16 networks with random fill-rule
+weights, against the reference's fp32 result.  Required: relative Frobenius error of the final fp32 sample <= 2.5e-2
+(measured 1.1e-2 .. 1.5e-2), and on the uint8 NHWC image >= 98.5 % of pixels within 8 levels, >= 90 % within 2
+(measured: see the printed histograms; the BASELINE-size loops in test_hip_fullsize.py give 99.3 % / 95.5 %).
+SURVEY section 7 proposed <= 2/255 for >= 99.9 % of pixels: out of reach for ANY 8-bit-mantissa torso -- one bf16 UNet
+evaluation differs from fp32 by 1.0e-2 relative (the reference's own fp16 torso: 1.4e-3), 4 steps compound to 1.1e-2 of
+an image whose range is 255 levels, i.e. an RMS error of ~1.5 levels with a tail; the same loop with the guidance
+gradient of the fp32 oracle injected instead of the bf16 one has the same error (test_hip_fullsize.py prints both), so
+the bf16 gradient is not what limits it.  FID parity is "unpinned" (no Inception graph / reference statistics offline).
 """
 import copy
 
@@ -47,10 +52,12 @@ def _check(sample, u8, g, tag):
     ref = torch.from_numpy(g[f"{tag}_sample"])
     r = ((sample.cpu() - ref).norm() / ref.norm()).item()
     print(tag, "rel fro", r)
-    assert r < 4e-2, (tag, r)
+    assert r < 2.5e-2, (tag, r)
     if f"{tag}_uint8" in g.files:
         d = np.abs(u8.cpu().numpy().astype(int) - g[f"{tag}_uint8"].astype(int))
-        assert (d <= 8).mean() >= 0.97, (tag, (d <= 8).mean())
+        hist = {k: round(float((d <= k).mean()), 4) for k in (0, 1, 2, 4, 8)}
+        print(tag, "uint8 within k levels", hist)
+        assert hist[8] >= 0.985 and hist[2] >= 0.90, (tag, hist)
 
 
 def test_guided_and_unguided_loops_match_reference_golden():
@@ -121,7 +128,7 @@ def test_unconditional_uniform_ddim4_and_return_all_images():
         ref = torch.from_numpy(g[f"{name}_sample"])
         r = ((sample.cpu() - ref).norm() / ref.norm()).item()
         print(name, "uncond rel fro", r)
-        assert r < 4e-2
+        assert r < 2.5e-2
     imgs = diffusion.ddim_sample_loop(model, (2, 3, 32, 32), noise=x_T, model_kwargs={}, return_all_images=True)
     assert len(imgs) == 5 and torch.equal(imgs[0], x_T)  # AutoDiffusion yields the start noise first
     dd = copy.deepcopy(diffusion)
