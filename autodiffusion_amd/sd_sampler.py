@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes as C
 import itertools
 
+import os
+
 import numpy as np
 import torch
 
@@ -130,6 +132,9 @@ def sd_step(x, eps, batch, cfg_scale, weights, hist, a_t, a_prev, sigma, noise=N
     return x_prev, pred, e_out
 
 
+_SIDE_STREAMS = {}  # device -> second HIP stream for the unconditional half of a guided evaluation
+
+
 class _LatentSampler:
     def __init__(self, model, schedule="linear", **kwargs):
         self.model = model
@@ -153,14 +158,35 @@ class _LatentSampler:
         if bad:
             raise NotImplementedError(f"{type(self).__name__}: {bad} are not built on the HIP path (unused by search_ea.py)")
 
+    # Classifier-free guidance evaluates the UNet on [uncond | cond] (ddim.py:177-181 concatenates them into one batch of
+    # 2N).  At the search's n_samples (6 latents) most launches of that batch under-fill 256 CUs, so the two halves run as
+    # two evaluations of N on two HIP streams instead (each stream replays its own captured graph: sd_unet.py keys graphs
+    # and conditioning projections by the launching stream) and fill each other's tails.  Bit-identical: every kernel's
+    # arithmetic per latent is independent of the batch it rides in.  ADM_SD_SPLIT_GUIDANCE=0 restores the single batch.
+    split_guidance = os.environ.get("ADM_SD_SPLIT_GUIDANCE", "1") != "0"
+
     def _begin(self, c, uc, scale):
         """Per sample() call: the guidance batch [uncond | cond] of the conditioning is built once, and models that
         take a ``context_key`` (LatentDiffusion over the HIP UNet) are told that it stays fixed for the call's steps."""
         self._guided = not (uc is None or scale == 1.)
-        self._c_in = torch.cat([uc, c]) if self._guided else c
+        self._split = bool(self._guided and self.split_guidance and c.is_cuda and getattr(self.model, "accepts_context_key", False))
+        self._c, self._uc = c, uc
+        self._c_in = torch.cat([uc, c]) if (self._guided and not self._split) else c
         self._key = ("sample", next(_CALL_IDS)) if getattr(self.model, "accepts_context_key", False) else None
 
     def _eps(self, x, t):
+        if self._guided and self._split:
+            cur = torch.cuda.current_stream(x.device)
+            side = _SIDE_STREAMS.get(x.device)
+            if side is None:
+                side = _SIDE_STREAMS[x.device] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                eu = self.model.apply_model(x, t, self._uc, context_key=(self._key, "u"))
+            ec = self.model.apply_model(x, t, self._c, context_key=(self._key, "c"))
+            cur.wait_stream(side)
+            eu.record_stream(cur)
+            return torch.cat([eu, ec])
         if self._guided:
             x, t = torch.cat([x] * 2), torch.cat([t] * 2)
         if self._key is not None:

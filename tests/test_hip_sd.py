@@ -292,3 +292,29 @@ def test_same_shape_evaluations_from_two_streams_use_disjoint_graphs():
         torch.cuda.synchronize()
         assert torch.equal(outs["a"], want_a) and torch.equal(outs["b"], want_b), rounds
     assert len(m._packed.graphs) == 2
+
+
+def test_split_stream_guidance_is_bit_identical():
+    """Classifier-free guidance as two evaluations of N latents on two HIP streams (the default) against the reference's
+    single batch of 2N (ddim.py:177-181), eager and with per-stream hipGraph replay, for the three samplers."""
+    from autodiffusion_amd.sd_sampler import DDIMSampler, DPMSolverSampler, LatentDiffusion, PLMSSampler, _LatentSampler
+    assert _LatentSampler.split_guidance is True
+    g, plan, P = sd_case("sd_unet_tiny")
+    unet = _model(plan, P)
+    ld = LatentDiffusion(unet, device=DEV)
+    x_T, ctx = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["context"]).to(DEV)
+    uc = ctx.flip(1).contiguous() * 0.5
+    for cls, cand in ((DDIMSampler, [153, 424, 690, 926]), (PLMSSampler, [153, 424, 690, 926]), (DPMSolverSampler, [999, 600, 300, 50, 1])):
+        outs = []
+        for split, graph in ((True, False), (False, False), (True, True), (False, True)):
+            unet.enable_graph(graph)
+            s = cls(ld)
+            s.split_guidance = split
+            out, _ = s.sample(S=len(cand) - (cls is DPMSolverSampler), batch_size=2, shape=[4, 16, 16], conditioning=ctx,
+                              verbose=False, x_T=x_T, unconditional_guidance_scale=3.0, unconditional_conditioning=uc,
+                              sampled_timestep=(cand if cls is DPMSolverSampler else np.array(cand)))
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), cls.__name__
+    unet.enable_graph(False)
