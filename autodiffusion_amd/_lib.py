@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")  # env override: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AdmError(RuntimeError):
@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
         ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
         ("cout", C.c_int32), ("taps", C.c_int32), ("prologue", C.c_int32), ("out_mode", C.c_int32),
         ("variant", C.c_int32), ("out_stats", C.c_void_p), ("w_packed32", C.c_void_p),
-        ("in_up", C.c_int32), ("res_up", C.c_int32),
+        ("in_up", C.c_int32), ("res_up", C.c_int32), ("ksplit", C.c_int32), ("ws", C.c_void_p),
     ]
 
 

@@ -66,8 +66,14 @@ struct ConvK {
   int out_mode;
   int in_up, res_up;         // the input (in0, no in1) / the residual is read through a virtual nearest-neighbour 2x upsample
   int ntiles16, nblocks_n;
-  int total_tiles;           // pixel tiles x Cout blocks (persistent launch: blocks walk this list)
+  int total_tiles;           // pixel tiles x Cout blocks (x K splits) (persistent launch: blocks walk this list)
   unsigned wbytes;
+  // split-K (3x3, small batches: a launch with few tiles but a long K loop): the tile list is multiplied by `ksplit`,
+  // split s runs chunks [s * cps, (s + 1) * cps) (cps even: the halo double buffer keeps its parity) from zero
+  // accumulators and stores them as fp32 [ksplit][N*H*W][Cout] into `ws`; conv_splitk_reduce adds the splits in a fixed
+  // order together with bias and residual, rounds to bf16 and accumulates the output statistics
+  int ksplit, cps;
+  float* ws;
 };
 
 // output-statistics slabs per tile: a 128-pixel tile is two 8x8 images (or two halves of one image)
@@ -212,6 +218,7 @@ conv_kernel(const ConvK p) {
 
   // ---- per-tile state (rewritten at every tile switch)
   int nb = 0, mt = 0, img0 = 0, y0 = 0, x0 = 0;
+  int sp = 0, cb = 0, ce = chunks;   // K split of the tile: chunks [cb, ce)
   __amdgpu_buffer_rsrc_t rs0 = rsw, rs1 = rsw;
   int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch / spare slot)
   // weight fragments go straight from the packed image (L2-resident, fragment-ordered: one 1 KB
@@ -220,6 +227,12 @@ conv_kernel(const ConvK p) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   // scalar part: tile -> Cout block, pixel-tile index, first image, origin
   auto tile_origin = [&](int lt, int& nb_, int& mt_, int& img0_, int& y0_, int& x0_) {
+    if (p.ksplit > 1) {
+      sp = lt % p.ksplit;
+      lt /= p.ksplit;
+      cb = sp * p.cps;
+      ce = cb + p.cps;
+    }
     nb_ = lt % p.nblocks_n;
     mt_ = lt / p.nblocks_n;
     if (p.TI == 1) {
@@ -260,10 +273,15 @@ conv_kernel(const ConvK p) {
     }
     // LDS-DMA of the tile's first chunk (see first_park): raw halo chunk 0, lane-linear into halo[0] ...
     const int seg_s = tid_s & (SEGP - 1), lane_s = tid_s & 63;
+    {
+      const bool first = cb < c0chunks;   // the tile's first chunk (chunk cb: 0 unless the K loop is split)
+      const int cs = first ? p.C0 : p.C1, co = (first ? cb : cb - c0chunks) * KCS;
+      const __amdgpu_buffer_rsrc_t rsf = first ? rs0 : rs1;
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * p.C0 + seg_s * 8) * 2u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (lds_ptr_t)(halo + (ps * NT + wave * 64) * 16), 16, (int)voff, 0, 0, 0);
+      for (int ps = 0; ps < PASSES; ++ps) {
+        const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg_s * 8) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsf, (lds_ptr_t)(halo + (ps * NT + wave * 64) * 16), 16, (int)voff, 0, 0, 0);
+      }
     }
     // ... and the affine tables of stages 0 and 1 (they are staged two stages ahead): the LDS table is
     // a[buf][ti][KCS] followed by b[buf][ti][KCS]; each half is 2*KCS lanes x 16 B, lane-linear, so KS
@@ -275,7 +293,7 @@ conv_kernel(const ConvK p) {
         const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(half == 0 ? p.aa : p.ab), 0, p.N * Cin * 4, 0x00020000);
         const int buf = idx / (TI_MAX * (KCS / 4)), ti = (idx / (KCS / 4)) % TI_MAX, part = idx % (KCS / 4);
         const int n = min(img0 + ti, p.N - 1);
-        const unsigned voff = ti < p.TI ? (unsigned)(n * Cin + min(buf, chunks - 1) * KCS + part * 4) * 4u : OOB;
+        const unsigned voff = ti < p.TI ? (unsigned)(n * Cin + min(cb + buf, ce - 1) * KCS + part * 4) * 4u : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_ptr_t)(abuf + half * (2 * TI_MAX * KCS) + (wave % KS) * 256), 16, (int)voff, 0, 0, 0);
       }
     }
@@ -389,8 +407,8 @@ conv_kernel(const ConvK p) {
   const int last = chunks - 1;
   auto first_loads = [&](int lq_) {
     if constexpr (TAPS == 9) {
-      load_w(0, wr[0]);
-      load_w(1, wr[1]);
+      load_w(cb * 9, wr[0]);
+      load_w(cb * 9 + 1, wr[1]);
     } else {
       if constexpr (KS == 1) {
         load_w(0, wr[0]);
@@ -412,7 +430,7 @@ conv_kernel(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int bch = nb * BN + (wn * TN + j) * 16 + lq_ * 4;
-      const uint4 b = bufload16(rsb, bch + 3 < p.Cout ? (unsigned)bch * 4u : OOB, 0);
+      const uint4 b = bufload16(rsb, (bch + 3 < p.Cout && p.ksplit <= 1) ? (unsigned)bch * 4u : OOB, 0);  // split-K: the reduce adds the bias
       bs[j] = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
     }
   };
@@ -467,8 +485,8 @@ conv_kernel(const ConvK p) {
           if constexpr (MORE && PRO != 0) {
             // affine table of chunk c+2 -> abuf[hb] (its readers, chunk c-1's transforms, are behind the last
             // barrier): fetched at tap 0, parked at tap 7 so that no wave ever waits on that load
-            if (t == 0 && c + 2 < chunks) affv = affine_load(c + 2, img0);
-            if (t == 7 && c + 2 < chunks) affine_park(affv, hb);
+            if (t == 0 && c + 2 < ce) affv = affine_load(c + 2, img0);
+            if (t == 7 && c + 2 < ce) affine_park(affv, hb);
           }
           if constexpr (MORE) {
             if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
@@ -478,8 +496,8 @@ conv_kernel(const ConvK p) {
         }
         __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
       };
-      for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::true_type{});
-      chunk(chunks - 1, std::false_type{});
+      for (int c = cb; c + 1 < ce; ++c) chunk(c, std::true_type{});
+      chunk(ce - 1, std::false_type{});
     } else {
       // 1x1: a stage is KS K-steps (KS*TM*TN MFMAs per wave) and ends in the loop's only barrier, so HBM/L2
       // latency must be covered by depth, not by taps: activation segments are fetched 2 stages ahead (register
@@ -566,7 +584,7 @@ conv_kernel(const ConvK p) {
     // ---- tile switch.  Every wave is behind the K loop's last barrier: both halo buffers and abuf are free.
     const int ltile_done = ltile;
     (void)ltile_done;
-    if (p.out_mode == 0) {
+    if (p.out_mode == 0 && p.ksplit <= 1) {
       // bf16 NHWC: the whole tile (acc + bias, bf16) is staged in LDS in ONE round and leaves as whole pixel
       // rows with 16-byte lanes (BN*2 contiguous bytes per pixel); the residual operand is fetched with the
       // same coalesced shape before the staging barrier, so that its latency overlaps the LDS round trip.
@@ -714,6 +732,30 @@ conv_kernel(const ConvK p) {
         }
       }
       ADM_TSTAMP(ltile_done, 6);
+    } else if (p.ksplit > 1) {
+      // split-K partial sums: fp32 [split][pixel][Cout], 16 bytes per lane (4 consecutive channels of one pixel)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 16 + lc;
+        const int ti = m >> p.thw_shift, rem = m & ((1 << p.thw_shift) - 1);
+        const int n = img0 + ti, y = y0 + (rem >> p.tw_shift), x = x0 + (rem & ((1 << p.tw_shift) - 1));
+        if (n >= p.N) continue;
+        float* row = p.ws + ((long long)sp * p.N * HWimg + ((long long)n * p.H + y) * p.W + x) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int ch0 = nb * BN + (wn * TN + j) * 16 + lq * 4;
+          if (ch0 + 3 < p.Cout) *reinterpret_cast<float4*>(row + ch0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+      }
+      if (more) {
+        tl = tnext;
+        ltile = tstart + tl;
+        tile_origin(ltile, nb, mt, img0, y0, x0);
+        tile_setup();
+        first_loads(lq);
+        __syncthreads();
+        first_park();
+      }
     } else {
       // fp32 NCHW (output head / stem backward): few channels, direct stores
 #pragma unroll
@@ -1033,6 +1075,69 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
   }
 }
 
+// Second half of a split-K conv: out[pixel][c] = bf16(bias[c] + sum_s ws[s][pixel][c]) (+ res), splits added in
+// index order (deterministic), plus the output statistics of the fused-GroupNorm hand-over: per (image, slab, channel)
+// sum and sum of squares of the bf16 values written, slab = a contiguous run of HW / slabs pixels (the consumer only adds
+// the slabs up).  One block per (64-channel group, slab, image): 8 threads x 8 channels across, 32 pixel lanes down.
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce(const float* __restrict__ ws, int ksplit, const float* __restrict__ bias, const uint16_t* __restrict__ res,
+                   uint16_t* __restrict__ out, float* __restrict__ stats, int n_img, int hw, int cout, int slabs) {
+  __shared__ float red[32][64][2];
+  const int g8 = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int ch = blockIdx.x * 64 + g8 * 8;
+  const int slab = blockIdx.y, img = blockIdx.z;
+  const int per = (hw + slabs - 1) / slabs;
+  const int p_begin = slab * per, p_end = min(hw, p_begin + per);
+  const long long split_stride = (long long)n_img * hw * cout;
+  const bool act = ch < cout;
+  float t1[8] = {}, t2[8] = {};
+  if (act) {
+    float b8[8];
+    *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(bias + ch);
+    *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(bias + ch + 4);
+    for (int px = p_begin + lane; px < p_end; px += 32) {
+      const long long e = ((long long)img * hw + px) * cout + ch;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = b8[j];
+      for (int sidx = 0; sidx < ksplit; ++sidx) {
+        const float4 a = *reinterpret_cast<const float4*>(ws + sidx * split_stride + e);
+        const float4 b = *reinterpret_cast<const float4*>(ws + sidx * split_stride + e + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+      uint32_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (uint32_t)adm_f32_to_bf16(v[2 * j]) | ((uint32_t)adm_f32_to_bf16(v[2 * j + 1]) << 16);
+      if (res) {   // as the one-pass epilogue: the conv result is rounded to bf16 first, then the residual is added
+        const uint4 rv = *reinterpret_cast<const uint4*>(res + e);
+        const uint32_t r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(o[j] << 16) + __uint_as_float(r4[j] << 16);
+          const float hi = __uint_as_float(o[j] & 0xffff0000u) + __uint_as_float(r4[j] & 0xffff0000u);
+          o[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + e) = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(o[j] << 16), hi = __uint_as_float(o[j] & 0xffff0000u);
+        t1[2 * j] += lo; t2[2 * j] += lo * lo; t1[2 * j + 1] += hi; t2[2 * j + 1] += hi * hi;
+      }
+    }
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[lane][g8 * 8 + j][0] = t1[j]; red[lane][g8 * 8 + j][1] = t2[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {   // fixed-order sum over the 32 pixel lanes: bitwise reproducible
+    const int c = threadIdx.x >> 1, q = threadIdx.x & 1;
+    float t = 0.0f;
+    for (int l = 0; l < 32; ++l) t += red[l][c][q];
+    if (blockIdx.x * 64 + c < cout) stats[(((long long)img * slabs + slab) * cout + blockIdx.x * 64 + c) * 2 + q] = t;
+  }
+}
+
 template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO, int KS>
 int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int NT = 64 * WM * WN;
@@ -1057,7 +1162,7 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   }
   ConvK kk = k;
   kk.nblocks_n = (k.Cout + BN - 1) / BN;
-  const long long tiles = (long long)m_tiles * kk.nblocks_n;
+  const long long tiles = (long long)m_tiles * kk.nblocks_n * (k.ksplit > 1 ? k.ksplit : 1);
   ADM_REQUIRE(tiles < (1ll << 31), ADM_E_SHAPE, "adm_conv: too many tiles");
   kk.total_tiles = (int)tiles;
   unsigned blocks = (unsigned)(tiles < slots ? tiles : slots);
@@ -1239,6 +1344,18 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE(!(k.in_up || k.res_up) || (a->taps == 9 && a->out_mode == 0 && a->c1 == 0 && a->h % 2 == 0 && a->w % 2 == 0 && a->h >= 16 && a->w >= 16),
               ADM_E_SHAPE, "adm_conv: in_up / res_up need a 3x3 conv with bf16 output, one input source and an even map >= 16x16");
   ADM_REQUIRE(!k.res_up || a->res, ADM_E_ARG, "adm_conv: res_up without a residual operand");
+  k.ksplit = a->ksplit > 1 ? a->ksplit : 1;
+  k.cps = 0;
+  k.ws = a->ws;
+  if (k.ksplit > 1) {
+    const int chunks = (a->c0 + a->c1) / KC;
+    ADM_REQUIRE(a->taps == 9 && a->out_mode == 0 && !k.res_up && a->ws, ADM_E_ARG,
+                "adm_conv: ksplit needs a 3x3 conv with bf16 output, no res_up and a workspace");
+    ADM_REQUIRE(chunks % k.ksplit == 0 && (chunks / k.ksplit) % 2 == 0, ADM_E_SHAPE,
+                "adm_conv: ksplit %d does not divide the %d 32-channel chunks into even runs", k.ksplit, chunks);
+    ADM_REQUIRE(a->cout % 8 == 0 && a->cout <= 2048 && adm_aligned16(a->ws), ADM_E_SHAPE, "adm_conv: ksplit needs cout %% 8 == 0, cout <= 2048, aligned ws");
+    k.cps = chunks / k.ksplit;
+  }
   k.ntiles16 = (a->cout + 15) / 16;
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
   hipStream_t s = (hipStream_t)stream;
@@ -1247,6 +1364,11 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   if (a->out_stats) {
     k.stat_slabs = stat_slabs_for(a, variant);
     ADM_REQUIRE(k.stat_slabs > 0, ADM_E_SHAPE, "adm_conv: fused output statistics are not offered for this shape / variant");
+  }
+  if (k.ksplit > 1) {
+    ADM_REQUIRE(variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: ksplit needs tiling variant 5 or 6");
+    k.res = nullptr;      // bias, residual and statistics belong to the reduce pass
+    k.stats = nullptr;
   }
   ADM_REQUIRE(!(k.in_up || k.res_up) || variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: in_up / res_up need tiling variant 5 or 6");
   if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
@@ -1263,6 +1385,17 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   }
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
   const bool small_map = a->h * a->w <= 64;
+  if (k.ksplit > 1) {
+    int rc;
+    if (variant == 5) rc = small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, 9, a->prologue, s);
+    else rc = small_map ? dispatch_conv<2, 4, 4, 2, 2>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2>(k, 9, a->prologue, s);
+    if (rc != 0) return rc;
+    const int hw = a->h * a->w;
+    const int slabs = a->out_stats ? stat_slabs_for(a, variant) : (hw >= 1024 ? hw / 256 : 1);
+    hipLaunchKernelGGL(conv_splitk_reduce, dim3((a->cout + 63) / 64, slabs, a->n), dim3(256), 0, s, (const float*)a->ws, k.ksplit, a->bias,
+                       a->res, reinterpret_cast<uint16_t*>(a->out), a->out_stats, a->n, hw, a->cout, slabs);
+    return adm_check_launch("adm_conv(split-K reduce)");
+  }
   switch (variant) {
     case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, a->prologue, s);  // 256 x 16 (output head / stem backward)
     // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs

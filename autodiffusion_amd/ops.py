@@ -227,8 +227,20 @@ def pack_conv_weight32(w):
     return out
 
 
+def splitk_for(h: int, w: int, cin: int) -> int:
+    """Split-K factor of a 3x3 conv by SHAPE only (never by batch: the fp32 summation order, hence the result, must not
+    depend on how many images ride along): 4 on 8x8 maps, 2 on 16x16 maps, where the K loop divides into even runs of at
+    least 4 chunks.  For small-batch callers (the SD latent UNet at n_samples 6): a launch there has a handful of tiles
+    with 40-80-chunk K loops on 256 CUs."""
+    chunks = cin // 32
+    want = 4 if h * w <= 64 else (2 if h * w <= 256 else 1)   # measured on SD v1 at 6-latent half batches: 4 / 2 / none at 8x8 / 16x16 / 32x32
+    while want > 1 and (chunks % want or (chunks // want) % 2 or chunks // want < 4):
+        want //= 2
+    return max(1, want)
+
+
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
-         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False):
+         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): bf16 NHWC.  Returns bf16 NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].
@@ -257,6 +269,12 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     a.in_up, a.res_up = int(in_up), int(res_up)
+    ws = None
+    if ksplit > 1:
+        if taps != 9 or out_f32_nchw or res_up:
+            raise AdmError("conv(ksplit > 1): 3x3 convs with bf16 output only")
+        ws = torch.empty((ksplit, n * h * w, cout), dtype=torch.float32, device=dev)
+        a.ksplit, a.ws = int(ksplit), ws.data_ptr()
     if in_up or res_up:
         w_packed32 = None  # the 32x32x16 kernel does not take the virtual upsample
     if variant == 0:

@@ -167,7 +167,8 @@ class UNetModel(HipModule):
     def _resblock(self, pr, s: SDResBlockSpec, x0, x1, emb):
         d = pr.blocks[s.prefix]
         aff1 = ops.gn_affine(x0, d["g1"], d["b1"], x1)
-        h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True, want_stats=True)
+        h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, x1=x1, aff=aff1, silu=True, want_stats=True,
+                     ksplit=self._ks(x0, x0.shape[3] + (0 if x1 is None else x1.shape[3])))
         off = pr.emb_off[s.prefix]
         aff2 = ops.gn_affine(h, d["g2"], d["b2"], add=emb[:, off:off + s.cout])
         if s.has_skip_conv:
@@ -175,7 +176,8 @@ class UNetModel(HipModule):
         else:
             assert x1 is None
             res = x0
-        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True)
+        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True,
+                        ksplit=self._ks(h, h.shape[3]))
 
     def _transformer(self, pr, s: SDTransformerSpec, x, kvs, n_ctx):
         d = pr.blocks[s.prefix]
@@ -225,6 +227,19 @@ class UNetModel(HipModule):
 
     # ------------------------------------------------------------------ forward
     use_graph = False  # replay one captured hipGraph per input shape (set by .enable_graph())
+
+    small_batch_splitk = False  # split the K loop of the 8x8 / 16x16-level 3x3 convs (set by .enable_splitk())
+
+    def enable_splitk(self, flag: bool = True):
+        """For the search's batch (n_samples 6, i.e. 6-latent half batches under guidance): the 3x3 convs of the 8x8 and
+        16x16 levels launch 30-60 tiles with 40-80-chunk K loops on 256 CUs; their K loops are cut into 4 / 2 runs that go
+        out as separate tiles (`ops.splitk_for`: by shape only, so results do not depend on the batch size) and a reduce
+        pass adds them.  Changes the fp32 summation order of those layers (deterministic; the parity tests hold either way)."""
+        self.small_batch_splitk = bool(flag)
+        return self
+
+    def _ks(self, t, cin):
+        return ops.splitk_for(t.shape[1], t.shape[2], cin) if self.small_batch_splitk else 1
 
     def enable_graph(self, flag: bool = True):
         """Capture the ~700 launches of one evaluation in a hipGraph per (latent shape, context shape) and replay it:

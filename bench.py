@@ -165,7 +165,7 @@ def run_sd(args, rank, world, dev, red_dev):
     from autodiffusion_amd.sd_unet import UNetModel
     n = args.batch or 6
     unet = UNetModel(image_size=32, use_spatial_transformer=True, **SD_V1).to(dev)
-    unet.randomize_(1234).enable_graph()
+    unet.randomize_(1234).enable_graph().enable_splitk(os.environ.get("ADM_SD_SPLITK", "1") != "0")
     sampler = DDIMSampler(LatentDiffusion(unet, device=dev))
     g = torch.Generator(device=dev).manual_seed(99)
     c, uc = (torch.randn(n, 77, 768, device=dev, generator=g) for _ in range(2))
@@ -196,6 +196,7 @@ def run_sd(args, rank, world, dev, red_dev):
     roof = None
     if not args.no_kernel_events:  # per-launch HIP events need the eager path: one untimed evaluation outside the graph
         unet.enable_graph(False)
+        unet.enable_splitk(False)   # the roofline kernel's launches are the one-pass ones
         ops.CONV_PROFILE = []
         x = torch.randn(2 * n, 4, 64, 64, device=dev)
         unet(x, torch.full((2 * n,), 500, device=dev, dtype=torch.int64), torch.cat([uc, c]))

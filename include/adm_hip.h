@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 2   /* 2: adm_conv_args gained in_up / res_up */
+#define ADM_ABI_VERSION 3   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -161,6 +161,11 @@ typedef struct adm_conv_args {
                         prologue is applied on the way): ResBlock(up=True)'s h_upd(in_layers[:-1](x)) without the
                         upsampled tensor ever existing.  3x3, bf16 output, c1 == 0, variant 0/5/6 only */
   int32_t res_up;    /* 1: res is [n][h/2][w/2][cout], added through the same virtual upsample (x_upd(x)) */
+  int32_t ksplit;    /* > 1: split-K for small batches (3x3, bf16 output, variant 5 / 6): the K loop of every output tile is
+                        cut into `ksplit` runs of (c0 + c1) / 32 / ksplit chunks (an even count) that run as separate
+                        tiles into `ws`, and a reduce pass adds them in index order with bias, residual and the output
+                        statistics.  Deterministic; the result depends on ksplit (fp32 summation order), not on n */
+  float* ws;         /* split-K workspace: fp32 [ksplit][n*h*w][cout], caller-owned */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

@@ -356,3 +356,55 @@ def test_conv_fused_output_statistics_feed_groupnorm(ops, n, hw, cin, cout, taps
         ops.USE_FUSED_STATS = True
     torch.testing.assert_close(a1, a2, rtol=2e-5, atol=1e-6)
     torch.testing.assert_close(b1, b2, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,hw,c0,c1,cout,ks,pro,use_res", [
+    (3, 8, 256, 0, 192, 4, 2, True),        # 8x8 level, 128-pixel tiles (two images per tile), ragged last tile
+    (2, 16, 128, 128, 128, 2, 2, False),    # virtual concat: the split boundary is the boundary between the two sources
+    (5, 8, 512, 0, 320, 4, 0, True),        # 320 output channels: the last 128-wide Cout block is ragged
+    (1, 16, 64, 192, 256, 2, 1, True),      # the split falls inside the second source
+])
+def test_conv_split_k_matches_the_one_pass_conv(ops, n, hw, c0, c1, cout, ks, pro, use_res):
+    """adm_conv with ksplit > 1 (K loop of every tile cut into runs that go out as separate tiles, fp32 partial sums,
+    deterministic reduce with bias / residual / output statistics) against fp32 torch and against the one-pass kernel."""
+    cin = c0 + c1
+    x = bf(rnd((n, cin, hw, hw), 1))
+    w = bf(rnd((cout, cin, 3, 3), 2, (cin * 9) ** -0.5))
+    b = 0.1 * rnd((cout,), 3)
+    res = bf(rnd((n, cout, hw, hw), 4)) if use_res else None
+    a = 1 + 0.1 * rnd((n, cin), 5)
+    sh = 0.1 * rnd((n, cin), 6)
+    xin = x
+    if pro:
+        xin = a[:, :, None, None] * x + sh[:, :, None, None]
+        if pro == 2:
+            xin = F.silu(xin)
+        xin = bf(xin)
+    ref = F.conv2d(xin, w, b, padding=1)
+    if use_res:
+        ref = bf(ref) + res
+    xd = nhwc_dev(x)
+    x0, x1 = (xd[..., :c0].contiguous(), xd[..., c0:].contiguous()) if c1 else (xd, None)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    kw = dict(x1=x1, aff=(a.to(DEV), sh.to(DEV)) if pro else None, silu=(pro == 2), res=nhwc_dev(res) if use_res else None,
+              want_stats=True)
+    y1 = ops.conv(x0, wp, b.to(DEV), cout, 9, **kw)
+    yk = ops.conv(x0, wp, b.to(DEV), cout, 9, ksplit=ks, **kw)
+    assert_close_bf16(nchw_cpu(yk), ref, f"split-K x{ks}")
+    d = (nchw_cpu(yk) - nchw_cpu(y1)).abs().max().item()
+    assert d <= 2e-2 * ref.abs().max().item(), d          # same values up to the last bf16 digit (fp32 order differs)
+    assert torch.equal(ops.conv(x0, wp, b.to(DEV), cout, 9, ksplit=ks, **kw), yk)   # deterministic
+    if n > 1:   # the result does not depend on the batch the image rides in
+        kw1 = dict(kw, x1=None if x1 is None else x1[:1].contiguous(), aff=None if not pro else (a[:1].to(DEV), sh[:1].to(DEV)),
+                   res=None if not use_res else nhwc_dev(res[:1]))
+        assert torch.equal(ops.conv(x0[:1].contiguous(), wp, b.to(DEV), cout, 9, ksplit=ks, **kw1), yk[:1])
+    # the reduce pass's output statistics feed GroupNorm like the one-pass epilogue's
+    gamma, beta = (1 + 0.2 * rnd((cout,), 7)).to(DEV), (0.1 * rnd((cout,), 8)).to(DEV)
+    a1, b1 = ops.gn_affine(yk, gamma, beta)
+    ops.USE_FUSED_STATS = False
+    try:
+        a2, b2 = ops.gn_affine(yk, gamma, beta)
+    finally:
+        ops.USE_FUSED_STATS = True
+    torch.testing.assert_close(a1, a2, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(b1, b2, rtol=2e-4, atol=2e-5)
