@@ -10,6 +10,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")  # env override: A/B builds
+# the same kernels built with IEEE half as the 16-bit element type (csrc/adm_common.h, -DADM_ACT_F16): the reference's own
+# torso precision (use_fp16=True); selected per tensor dtype by ops.py, per model by `torso="fp16"` / ADM_TORSO=fp16
+LIB_PATH_F16 = os.environ.get("ADM_HIP_LIB_F16") or os.path.join(_HERE, "libadm_hip_f16.so")
 ABI_VERSION = 3
 
 
@@ -92,14 +95,14 @@ SIGNATURES = {
     "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """Load (once) and type the shared library; raise AdmError if it is unusable."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(kind: str = "bf16") -> C.CDLL:
+    """Load (once) and type the shared library of the given element type; raise AdmError if it is unusable."""
+    if kind in _libs:
+        return _libs[kind]
+    LIB_PATH = {"bf16": globals()["LIB_PATH"], "f16": LIB_PATH_F16}[kind]
     # PyTorch-ROCm ships its own libamdhip64.so.7; import it FIRST so that the dynamic loader binds
     # our library to the same HIP runtime instance (shared streams / device pointers).  Loading ours
     # first would bring in /opt/rocm's copy and leave torch without a usable device.
@@ -119,8 +122,8 @@ def load() -> C.CDLL:
         fn.argtypes = args
     v = lib.adm_abi_version()
     if v != ABI_VERSION:
-        raise AdmError(f"libadm_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
-    _lib = lib
+        raise AdmError(f"{os.path.basename(LIB_PATH)} ABI {v} != expected {ABI_VERSION}; rebuild")
+    _libs[kind] = lib
     return lib
 
 

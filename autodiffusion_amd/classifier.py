@@ -38,8 +38,8 @@ class EncoderUNetModel(AdmNet):
         wc = f32(f"{p}.2.c_proj.weight").reshape(h.out_dim, h.channels).contiguous()
         pr.head = dict(
             g=f32(f"{p}.0.weight"), b=f32(f"{p}.0.bias"), pos=f32(f"{p}.2.positional_embedding"),
-            wqkv=ops.pack_conv_weight(P[f"{p}.2.qkv_proj.weight"]), bqkv=f32(f"{p}.2.qkv_proj.bias"),
-            wqkv_bwd=ops.pack_conv_weight_bwd(P[f"{p}.2.qkv_proj.weight"]),
+            wqkv=ops.pack_conv_weight(P[f"{p}.2.qkv_proj.weight"], self.compute_dtype), bqkv=f32(f"{p}.2.qkv_proj.bias"),
+            wqkv_bwd=ops.pack_conv_weight_bwd(P[f"{p}.2.qkv_proj.weight"], self.compute_dtype),
             wc=wc, bc=f32(f"{p}.2.c_proj.bias"), wc_t=wc.t().contiguous(),
         )
         pr.zero_bias = torch.zeros(max(pr.zero_bias.numel(), 3 * h.channels), dtype=torch.float32,

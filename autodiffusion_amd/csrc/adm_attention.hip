@@ -85,14 +85,14 @@ attn_kernel_v1(const AttnK p) {
   // one descriptor over this image's T rows: queries / keys beyond T read as zeros (no bounds branches)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
   // Q^T fragments: lane (query lc, quarter lq) holds Q[query][ks*32 + 8*lq .. +8]
-  bf16x8 qf[2][KS];
+  adm_h8 qf[2][KS];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qbase + qt * 16 + lc;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
-      qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
+      qf[qt][ks] = __builtin_bit_cast(adm_h8, v);
     }
   }
   adm_s16x4 qf16[2] = {};  // the 16-deep tail: lane (query lc, quarter lq) holds Q[query][32*KS + 4*lq .. +4]
@@ -136,12 +136,12 @@ attn_kernel_v1(const AttnK p) {
     //      read latency 8 times per tile); the V^T fragments are requested right after the S MFMAs so that
     //      their latency hides under the softmax VALU work.
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 kfr[4][KS];
+    adm_h8 kfr[4][KS];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
-        kfr[kt][ks] = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+        kfr[kt][ks] = *reinterpret_cast<const adm_h8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
     adm_s16x4 kfr16[4] = {};
     if constexpr (R16) {
 #pragma unroll
@@ -155,20 +155,20 @@ attn_kernel_v1(const AttnK p) {
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
-        st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt][0], qf[qt][0], zero4, 0, 0, 0);
+        st[kt][qt] = adm_mfma_16x16x32(kfr[kt][0], qf[qt][0], zero4, 0, 0, 0);
 #pragma unroll
       for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
+          st[kt][qt] = adm_mfma_16x16x32(kfr[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
       if constexpr (R16) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kfr16[kt], qf16[qt], st[kt][qt], 0, 0, 0);
+          st[kt][qt] = adm_mfma_16x16x16(kfr16[kt], qf16[qt], st[kt][qt], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 vfr[DT][2];
+    adm_h8 vfr[DT][2];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -176,7 +176,7 @@ attn_kernel_v1(const AttnK p) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- online softmax (per query column)
     const bool ragged = k0 + KT > p.Tk;
-    bf16x8 pf[2][2];  // [query tile][32-key block]
+    adm_h8 pf[2][2];  // [query tile][32-key block]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float mx = -1e30f;
@@ -219,9 +219,9 @@ attn_kernel_v1(const AttnK p) {
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        bf16x8 f;
+        adm_h8 f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (__bf16)pv[2 * kb + (e >> 2)][e & 3];
+        for (int e = 0; e < 8; ++e) f[e] = (adm_elem_t)pv[2 * kb + (e >> 2)][e & 3];
         pf[qt][kb] = f;
       }
     }
@@ -234,7 +234,7 @@ attn_kernel_v1(const AttnK p) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
+          oacc[dt][qt] = adm_mfma_16x16x32(vfr[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
     if (next) {
       kr.store(Ks[cur ^ 1], KROW, tid);
       vr.store(Vs[cur ^ 1], KROW, tid);
@@ -256,8 +256,8 @@ attn_kernel_v1(const AttnK p) {
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 o = oacc[dt][qt] * inv;
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+      pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
       *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
     }
   }
@@ -326,14 +326,14 @@ attn_kernel(const AttnK p) {
   // one descriptor over this image's T rows: queries / keys beyond T read as zeros (no bounds branches)
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
   // Q^T fragments: lane (query lc, quarter lq) holds Q[query][ks*32 + 8*lq .. +8]
-  bf16x8 qf[2][KS];
+  adm_h8 qf[2][KS];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qbase + qt * 16 + lc;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
-      qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
+      qf[qt][ks] = __builtin_bit_cast(adm_h8, v);
     }
   }
   adm_s16x4 qf16[2] = {};  // the 16-deep tail: lane (query lc, quarter lq) holds Q[query][32*KS + 4*lq .. +4]
@@ -356,7 +356,7 @@ attn_kernel(const AttnK p) {
   }
   float m_run[2] = {0.f, 0.f};
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const bf16x8 ones = __builtin_bit_cast(bf16x8, s16x8{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+  const adm_h8 ones = __builtin_bit_cast(adm_h8, s16x8{ADM_ONE16, ADM_ONE16, ADM_ONE16, ADM_ONE16, ADM_ONE16, ADM_ONE16, ADM_ONE16, ADM_ONE16});
   const float thr_raw = MOVE_THR / p.scale_log2;
 
   const int ntiles = (p.Tk + KT - 1) / KT;
@@ -411,7 +411,7 @@ attn_kernel(const AttnK p) {
     // per SIMD; the loop is latency-bound, and the third wave is worth more than the wider read-ahead.
     // (Head widths with a 16-deep tail keep all four fragment sets: they are not on a hot path.)
     constexpr int NSET = R16 ? 4 : 2;
-    bf16x8 kfr[NSET][KS];
+    adm_h8 kfr[NSET][KS];
     adm_s16x4 kfr16[NSET] = {};
     auto kread = [&](int kt) {
       const int slot = kt % NSET;
@@ -420,7 +420,7 @@ attn_kernel(const AttnK p) {
 #if ADM_ATTN_ABL == 5
         kfr[slot][ks] = qf[0][ks];
 #else
-        kfr[slot][ks] = *reinterpret_cast<const bf16x8*>(
+        kfr[slot][ks] = *reinterpret_cast<const adm_h8*>(
             &Kc[(kt * 16 + lc) * KROW + (DMA ? ((ks * 4 + lq) ^ (lc & 7)) * 8 : ks * 32 + lq * 8)]);
 #endif
       if constexpr (R16) kfr16[slot] = *reinterpret_cast<const adm_s16x4*>(&Kc[(kt * 16 + lc) * KROW + KS * 32 + lq * 4]);
@@ -438,16 +438,16 @@ attn_kernel(const AttnK p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
-        st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt % NSET][0], qf[qt][0], cin[qt], 0, 0, 0);
+        st[kt][qt] = adm_mfma_16x16x32(kfr[kt % NSET][0], qf[qt][0], cin[qt], 0, 0, 0);
 #pragma unroll
       for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt % NSET][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
+          st[kt][qt] = adm_mfma_16x16x32(kfr[kt % NSET][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
       if constexpr (R16) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kfr16[kt % NSET], qf16[qt], st[kt][qt], 0, 0, 0);
+          st[kt][qt] = adm_mfma_16x16x16(kfr16[kt % NSET], qf16[qt], st[kt][qt], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -478,7 +478,7 @@ attn_kernel(const AttnK p) {
     __builtin_amdgcn_sched_barrier(0);
     // V^T fragments (transposing LDS read) roll through two register sets, one output d-tile ahead of the MFMAs; the
     // first set is requested here so that its latency hides under the softmax VALU work
-    bf16x8 vfr[2][2];
+    adm_h8 vfr[2][2];
     auto vread = [&](int dt, int slot) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -489,7 +489,7 @@ attn_kernel(const AttnK p) {
 #endif
     };
 #ifdef ADM_ATTN_NOROLLV
-    bf16x8 vall[DT][2];
+    adm_h8 vall[DT][2];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -545,20 +545,20 @@ attn_kernel(const AttnK p) {
     // ---- P = 2^((S - m) * scale_log2), rounded to bf16 straight into the B fragments of the second product
     //      (this file is built with -fno-slp-vectorize: hipcc otherwise pairs the multiplies into v_pk_mul_f32, which
     //      issues slower than two single multiplies beside MFMAs)
-    bf16x8 pf[2][2];  // [query tile][32-key block]
+    adm_h8 pf[2][2];  // [query tile][32-key block]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        bf16x8 f;
+        adm_h8 f;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #if ADM_ATTN_ABL == 1
-          f[e] = __builtin_bit_cast(__bf16, (uint16_t)(__float_as_uint(st[2 * kb + (e >> 2)][qt][e & 3]) >> 16));
+          f[e] = __builtin_bit_cast(adm_elem_t, (uint16_t)(__float_as_uint(st[2 * kb + (e >> 2)][qt][e & 3]) >> 16));
 #elif ADM_ATTN_ABL == 9
-          f[e] = (__bf16)(st[2 * kb + (e >> 2)][qt][e & 3] * p.scale_log2);
+          f[e] = (adm_elem_t)(st[2 * kb + (e >> 2)][qt][e & 3] * p.scale_log2);
 #else
-          f[e] = (__bf16)__builtin_amdgcn_exp2f(st[2 * kb + (e >> 2)][qt][e & 3] * p.scale_log2);
+          f[e] = (adm_elem_t)__builtin_amdgcn_exp2f(st[2 * kb + (e >> 2)][qt][e & 3] * p.scale_log2);
 #endif
         pf[qt][kb] = f;
       }
@@ -568,7 +568,7 @@ attn_kernel(const AttnK p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt][kb], lacc[qt], 0, 0, 0);
+      for (int qt = 0; qt < 2; ++qt) lacc[qt] = adm_mfma_16x16x32(ones, pf[qt][kb], lacc[qt], 0, 0, 0);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #ifndef ADM_ATTN_NOROLLV
@@ -580,9 +580,9 @@ attn_kernel(const AttnK p) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #ifdef ADM_ATTN_NOROLLV
-          oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vall[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
+          oacc[dt][qt] = adm_mfma_16x16x32(vall[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
 #else
-          oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt & 1][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
+          oacc[dt][qt] = adm_mfma_16x16x32(vfr[dt & 1][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -625,8 +625,8 @@ attn_kernel(const AttnK p) {
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 o = oacc[dt][qt] * inv;
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+      pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
       *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
     }
   }
@@ -655,11 +655,11 @@ attn_wide_kernel(const AttnK p) {
                                                                        p.Tk * p.Ckv * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
 
-  bf16x8 qf[KS];
+  adm_h8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
-    qf[ks] = __builtin_bit_cast(bf16x8, v);
+    qf[ks] = __builtin_bit_cast(adm_h8, v);
   }
   f32x4 oacc[DT];
 #pragma unroll
@@ -683,8 +683,8 @@ attn_wide_kernel(const AttnK p) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], st[kt], 0, 0, 0);
+        const adm_h8 kf = *reinterpret_cast<const adm_h8*>(&Ks[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+        st[kt] = adm_mfma_16x16x32(kf, qf[ks], st[kt], 0, 0, 0);
       }
     }
     if (k0 + KT2 > p.Tk) {
@@ -705,21 +705,21 @@ attn_wide_kernel(const AttnK p) {
     const float mneg = -m_new * p.scale_log2;
     m_run = m_new;
     float psum = 0.f;
-    bf16x8 pf;
+    adm_h8 pf;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float e = __builtin_amdgcn_exp2f(st[kt][r] * p.scale_log2 + mneg);
         psum += e;
-        pf[kt * 4 + r] = (__bf16)e;
+        pf[kt * 4 + r] = (adm_elem_t)e;
       }
     l_run = l_run * alpha + psum;
     // O^T += V^T . P^T; contraction slot k = 8*lq + e <-> key 16*(e>>2) + 4*lq + (e&3)
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      const bf16x8 vf = adm_tr_frag(Vs, KROW, 0, dt * 16, lc, lq);
-      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt] * alpha, 0, 0, 0);
+      const adm_h8 vf = adm_tr_frag(Vs, KROW, 0, dt * 16, lc, lq);
+      oacc[dt] = adm_mfma_16x16x32(vf, pf, oacc[dt] * alpha, 0, 0, 0);
     }
   }
   const float l = adm_quarter_sum(l_run);
@@ -731,8 +731,8 @@ attn_wide_kernel(const AttnK p) {
   for (int dt = 0; dt < DT; ++dt) {
     const f32x4 o = oacc[dt] * inv;
     uint2 pk;
-    pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
-    pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+    pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
+    pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
     *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
   }
 }

@@ -51,7 +51,7 @@ attn_dq_kernel(const AttnBwdK p) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, p.T * p.C * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (long long)n * p.T * p.C), 0, p.T * p.C * 2, 0x00020000);
-  bf16x8 qf[2][KS], gf[2][KS];
+  adm_h8 qf[2][KS], gf[2][KS];
   float lse[2], dl[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -65,12 +65,12 @@ attn_dq_kernel(const AttnBwdK p) {
       const adm_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
       const adm_u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(rsg, (q * p.C + hd * D + ks * 32 + lq * 8) * 2, 0, 0);
       const adm_u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rso, (q * p.C + hd * D + ks * 32 + lq * 8) * 2, 0, 0);
-      qf[qt][ks] = __builtin_bit_cast(bf16x8, a);
-      gf[qt][ks] = __builtin_bit_cast(bf16x8, g);
+      qf[qt][ks] = __builtin_bit_cast(adm_h8, a);
+      gf[qt][ks] = __builtin_bit_cast(adm_h8, g);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        dsum += __uint_as_float(o[e] << 16) * __uint_as_float(g[e] << 16);
-        dsum += __uint_as_float(o[e] & 0xffff0000u) * __uint_as_float(g[e] & 0xffff0000u);
+        dsum += adm_lo_f32(o[e]) * adm_lo_f32(g[e]);
+        dsum += adm_hi_f32(o[e]) * adm_hi_f32(g[e]);
       }
     }
     dsum = adm_quarter_sum(dsum);
@@ -102,7 +102,7 @@ attn_dq_kernel(const AttnBwdK p) {
     }
     const uint16_t* Kc = Ks[cur];
     const uint16_t* Vc = Vs[cur];
-    bf16x8 dsf[2][2];
+    adm_h8 dsf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x4 st[2][2], dp[2][2];  // [key tile within the 32-key block][query tile]
@@ -112,12 +112,12 @@ attn_dq_kernel(const AttnBwdK p) {
         const int kt = 2 * kb + kk;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+          const adm_h8 kf = *reinterpret_cast<const adm_h8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+          const adm_h8 vf = *reinterpret_cast<const adm_h8*>(&Vc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            st[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], ks == 0 ? zero4 : st[kk][qt], 0, 0, 0);
-            dp[kk][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[qt][ks], ks == 0 ? zero4 : dp[kk][qt], 0, 0, 0);
+            st[kk][qt] = adm_mfma_16x16x32(kf, qf[qt][ks], ks == 0 ? zero4 : st[kk][qt], 0, 0, 0);
+            dp[kk][qt] = adm_mfma_16x16x32(vf, gf[qt][ks], ks == 0 ? zero4 : dp[kk][qt], 0, 0, 0);
           }
         }
       }
@@ -136,9 +136,9 @@ attn_dq_kernel(const AttnBwdK p) {
             dsv[kk * 4 + 2 * h] = d2.x;
             dsv[kk * 4 + 2 * h + 1] = d2.y;
           }
-        bf16x8 f;
+        adm_h8 f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (__bf16)dsv[e];
+        for (int e = 0; e < 8; ++e) f[e] = (adm_elem_t)dsv[e];
         dsf[qt][kb] = f;
       }
     }
@@ -146,10 +146,10 @@ attn_dq_kernel(const AttnBwdK p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8 kt_f = adm_tr_frag(Kc, KROW, kb * 32, dt * 16, lc, lq);  // K^T from the row-major tile
+        const adm_h8 kt_f = adm_tr_frag(Kc, KROW, kb * 32, dt * 16, lc, lq);  // K^T from the row-major tile
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-          acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, dsf[qt][kb], acc[dt][qt], 0, 0, 0);
+          acc[dt][qt] = adm_mfma_16x16x32(kt_f, dsf[qt][kb], acc[dt][qt], 0, 0, 0);
       }
     if (next) {
       kr.store(Ks[cur ^ 1], KROW, tid);
@@ -166,8 +166,8 @@ attn_dq_kernel(const AttnBwdK p) {
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 o = acc[dt][qt] * p.inv_sqrt_d;
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_bf16(o[0]) | ((uint32_t)adm_f32_to_bf16(o[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_bf16(o[2]) | ((uint32_t)adm_f32_to_bf16(o[3]) << 16);
+      pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
       *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
     }
   }
@@ -194,7 +194,7 @@ attn_dkv_kernel(const AttnBwdK p) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)dbase, 0, p.T * p.C * 2, 0x00020000);
   // K^T / V^T B-operand fragments of this wave's 32 keys: lane (key lc, quarter lq) holds row[key][ks*32 + 8*lq ..]
-  bf16x8 kf[2][KS], vf[2][KS];
+  adm_h8 kf[2][KS], vf[2][KS];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
     const int key = kbase + kt * 16 + lc;
@@ -202,8 +202,8 @@ attn_dkv_kernel(const AttnBwdK p) {
     for (int ks = 0; ks < KS; ++ks) {
       const adm_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (key * p.C3 + kcol + ks * 32 + lq * 8) * 2, 0, 0);
       const adm_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (key * p.C3 + vcol + ks * 32 + lq * 8) * 2, 0, 0);
-      kf[kt][ks] = __builtin_bit_cast(bf16x8, a);
-      vf[kt][ks] = __builtin_bit_cast(bf16x8, b);
+      kf[kt][ks] = __builtin_bit_cast(adm_h8, a);
+      vf[kt][ks] = __builtin_bit_cast(adm_h8, b);
     }
   }
   f32x4 dv[DT][2], dk[DT][2];
@@ -242,7 +242,7 @@ attn_dkv_kernel(const AttnBwdK p) {
     const uint16_t* Gc = Gs[cur];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {     // 32-query block of the tile
-      bf16x8 pf[2], dsf[2];             // per key tile
+      adm_h8 pf[2], dsf[2];             // per key tile
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         f32x4 st[2], dp[2];              // the block's two 16-query tiles
@@ -252,14 +252,14 @@ attn_dkv_kernel(const AttnBwdK p) {
           const int qt = 2 * qb + qq;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-            const bf16x8 ga = *reinterpret_cast<const bf16x8*>(&Gc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-            st[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], ks == 0 ? zero4 : st[qq], 0, 0, 0);
-            dp[qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf[kt][ks], ks == 0 ? zero4 : dp[qq], 0, 0, 0);
+            const adm_h8 qa = *reinterpret_cast<const adm_h8*>(&Qc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+            const adm_h8 ga = *reinterpret_cast<const adm_h8*>(&Gc[(qt * 16 + lc) * KROW + ks * 32 + lq * 8]);
+            st[qq] = adm_mfma_16x16x32(qa, kf[kt][ks], ks == 0 ? zero4 : st[qq], 0, 0, 0);
+            dp[qq] = adm_mfma_16x16x32(ga, vf[kt][ks], ks == 0 ? zero4 : dp[qq], 0, 0, 0);
           }
         }
         // the 4 query rows of a lane quarter are consecutive: one 16-byte LDS read each for lse and delta
-        bf16x8 f, g;
+        adm_h8 f, g;
         const adm_f32x2 sc2 = {p.scale_log2, p.scale_log2};
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
@@ -272,20 +272,20 @@ attn_dkv_kernel(const AttnBwdK p) {
           const adm_f32x2 p1 = {__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
           const adm_f32x2 s0 = p0 * (adm_f32x2{dp[qq][0], dp[qq][1]} - adm_f32x2{d4.x, d4.y});
           const adm_f32x2 s1 = p1 * (adm_f32x2{dp[qq][2], dp[qq][3]} - adm_f32x2{d4.z, d4.w});
-          f[qq * 4 + 0] = (__bf16)p0.x; f[qq * 4 + 1] = (__bf16)p0.y; f[qq * 4 + 2] = (__bf16)p1.x; f[qq * 4 + 3] = (__bf16)p1.y;
-          g[qq * 4 + 0] = (__bf16)s0.x; g[qq * 4 + 1] = (__bf16)s0.y; g[qq * 4 + 2] = (__bf16)s1.x; g[qq * 4 + 3] = (__bf16)s1.y;
+          f[qq * 4 + 0] = (adm_elem_t)p0.x; f[qq * 4 + 1] = (adm_elem_t)p0.y; f[qq * 4 + 2] = (adm_elem_t)p1.x; f[qq * 4 + 3] = (adm_elem_t)p1.y;
+          g[qq * 4 + 0] = (adm_elem_t)s0.x; g[qq * 4 + 1] = (adm_elem_t)s0.y; g[qq * 4 + 2] = (adm_elem_t)s1.x; g[qq * 4 + 3] = (adm_elem_t)s1.y;
         }
         pf[kt] = f;
         dsf[kt] = g;
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const bf16x8 gt_f = adm_tr_frag(Gc, KROW, qb * 32, dt * 16, lc, lq);  // dA^T
-        const bf16x8 qt_f = adm_tr_frag(Qc, KROW, qb * 32, dt * 16, lc, lq);  // Q^T
+        const adm_h8 gt_f = adm_tr_frag(Gc, KROW, qb * 32, dt * 16, lc, lq);  // dA^T
+        const adm_h8 qt_f = adm_tr_frag(Qc, KROW, qb * 32, dt * 16, lc, lq);  // Q^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-          dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt_f, pf[kt], dv[dt][kt], 0, 0, 0);
-          dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf[kt], dk[dt][kt], 0, 0, 0);
+          dv[dt][kt] = adm_mfma_16x16x32(gt_f, pf[kt], dv[dt][kt], 0, 0, 0);
+          dk[dt][kt] = adm_mfma_16x16x32(qt_f, dsf[kt], dk[dt][kt], 0, 0, 0);
         }
       }
     }
@@ -302,11 +302,11 @@ attn_dkv_kernel(const AttnBwdK p) {
       const f32x4 a = dk[dt][kt] * p.inv_sqrt_d;
       const f32x4 b = dv[dt][kt];
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_bf16(a[0]) | ((uint32_t)adm_f32_to_bf16(a[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_bf16(a[2]) | ((uint32_t)adm_f32_to_bf16(a[3]) << 16);
+      pk.x = (uint32_t)adm_f32_to_h(a[0]) | ((uint32_t)adm_f32_to_h(a[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_h(a[2]) | ((uint32_t)adm_f32_to_h(a[3]) << 16);
       *reinterpret_cast<uint2*>(orow + kcol + dt * 16 + lq * 4) = pk;
-      pk.x = (uint32_t)adm_f32_to_bf16(b[0]) | ((uint32_t)adm_f32_to_bf16(b[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_bf16(b[2]) | ((uint32_t)adm_f32_to_bf16(b[3]) << 16);
+      pk.x = (uint32_t)adm_f32_to_h(b[0]) | ((uint32_t)adm_f32_to_h(b[1]) << 16);
+      pk.y = (uint32_t)adm_f32_to_h(b[2]) | ((uint32_t)adm_f32_to_h(b[3]) << 16);
       *reinterpret_cast<uint2*>(orow + vcol + dt * 16 + lq * 4) = pk;
     }
   }

@@ -25,20 +25,20 @@ __device__ __forceinline__ void adm_xcd_block(int& bx, int& by) {
 // i.e. "column col0+lc" for a k-order that matches a B operand taken straight from 16x16x32
 // accumulators (4 consecutive rows per lane quarter, two 16-row tiles per 32-deep k-step).
 // Each 16-lane group reads a 4-row x 16-column block; lane 4q+p supplies the address of row q, columns 4p..4p+3.
-__device__ __forceinline__ bf16x8 adm_tr_frag(const uint16_t* tile, int row_stride, int row0, int col0, int lc, int lq) {
+__device__ __forceinline__ adm_h8 adm_tr_frag(const uint16_t* tile, int row_stride, int row0, int col0, int lc, int lq) {
   const uint16_t* p0 = tile + (row0 + 4 * lq + (lc >> 2)) * row_stride + col0 + 4 * (lc & 3);
   const adm_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) adm_s16x4*)p0);
   const adm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) adm_s16x4*)(p0 + 16 * row_stride));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(adm_h8, v);
 }
 
 // The same fragment of a [rows][64] bf16 tile with UNPADDED 128-byte rows whose 16-byte segments are XOR-swizzled
 // (segment s of row r lives in slot s ^ (r & 7): the layout an LDS-DMA fill leaves, adm_attention.hip); row0 must be a
 // multiple of 8.  The 8-byte pieces of a lane group stay inside one segment, so the transposing read is unchanged.
-__device__ __forceinline__ bf16x8 adm_tr_frag_swz(const uint16_t* tile, int row0, int col0, int lc, int lq) {
+__device__ __forceinline__ adm_h8 adm_tr_frag_swz(const uint16_t* tile, int row0, int col0, int lc, int lq) {
   const int r = 4 * lq + (lc >> 2);                         // row within the 16-row block (row0 = 0 mod 8: r & 7 decides)
   const int seg = ((col0 >> 3) + ((lc & 3) >> 1)) ^ (r & 7);
   const uint16_t* p0 = tile + (row0 + r) * 64 + seg * 8 + 4 * (lc & 1);
@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 adm_tr_frag_swz(const uint16_t* tile, int row0
   const adm_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) adm_s16x4*)(p0 + 16 * 64));
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(adm_h8, v);
 }
 
 // [ROWS x D] bf16 tile of a token-major tensor, register-staged: issue the loads early, write late.

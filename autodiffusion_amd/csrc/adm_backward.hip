@@ -57,8 +57,8 @@ gn_bwd_partial_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
       const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float x0 = __uint_as_float(xu[j] << 16), x1 = __uint_as_float(xu[j] & 0xffff0000u);
-        float g0 = __uint_as_float(gu[j] << 16) * dys, g1 = __uint_as_float(gu[j] & 0xffff0000u) * dys;
+        const float x0 = adm_lo_f32(xu[j]), x1 = adm_hi_f32(xu[j]);
+        float g0 = adm_lo_f32(gu[j]) * dys, g1 = adm_hi_f32(gu[j]) * dys;
         if (silu) {
           g0 *= silu_grad(a8[2 * j] * x0 + b8[2 * j]);
           g1 *= silu_grad(a8[2 * j + 1] * x1 + b8[2 * j + 1]);
@@ -155,17 +155,17 @@ gn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xx = (j & 1) ? __uint_as_float(xu[j >> 1] & 0xffff0000u) : __uint_as_float(xu[j >> 1] << 16);
-      float gg = ((j & 1) ? __uint_as_float(gu[j >> 1] & 0xffff0000u) : __uint_as_float(gu[j >> 1] << 16)) * dys;
-      const float ad = ((j & 1) ? __uint_as_float(au[j >> 1] & 0xffff0000u) : __uint_as_float(au[j >> 1] << 16)) * adds;
+      const float xx = (j & 1) ? adm_hi_f32(xu[j >> 1]) : adm_lo_f32(xu[j >> 1]);
+      float gg = ((j & 1) ? adm_hi_f32(gu[j >> 1]) : adm_lo_f32(gu[j >> 1])) * dys;
+      const float ad = ((j & 1) ? adm_hi_f32(au[j >> 1]) : adm_lo_f32(au[j >> 1])) * adds;
       if (silu) gg *= silu_grad(a8[j] * xx + b8[j]);
       r[j] = a8[j] * gg + k18[j] * xx + k08[j] + ad;
     }
     uint4 pk;
-    pk.x = adm_f32_to_bf16(r[0]) | ((uint32_t)adm_f32_to_bf16(r[1]) << 16);
-    pk.y = adm_f32_to_bf16(r[2]) | ((uint32_t)adm_f32_to_bf16(r[3]) << 16);
-    pk.z = adm_f32_to_bf16(r[4]) | ((uint32_t)adm_f32_to_bf16(r[5]) << 16);
-    pk.w = adm_f32_to_bf16(r[6]) | ((uint32_t)adm_f32_to_bf16(r[7]) << 16);
+    pk.x = adm_f32_to_h(r[0]) | ((uint32_t)adm_f32_to_h(r[1]) << 16);
+    pk.y = adm_f32_to_h(r[2]) | ((uint32_t)adm_f32_to_h(r[3]) << 16);
+    pk.z = adm_f32_to_h(r[4]) | ((uint32_t)adm_f32_to_h(r[5]) << 16);
+    pk.w = adm_f32_to_h(r[6]) | ((uint32_t)adm_f32_to_h(r[7]) << 16);
     *reinterpret_cast<uint4*>(out + pix * c + ch) = pk;
   }
 }
@@ -188,9 +188,9 @@ add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint1
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float lo = __uint_as_float(au[j] << 16) + bs * __uint_as_float(bu[j] << 16);
-      const float hi = __uint_as_float(au[j] & 0xffff0000u) + bs * __uint_as_float(bu[j] & 0xffff0000u);
-      o[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+      const float lo = adm_lo_f32(au[j]) + bs * adm_lo_f32(bu[j]);
+      const float hi = adm_hi_f32(au[j]) + bs * adm_hi_f32(bu[j]);
+      o[j] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
     }
     *reinterpret_cast<uint4*>(out + pix * c + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -236,11 +236,11 @@ pool_prep_kernel(const uint16_t* __restrict__ hsrc, const float* __restrict__ aa
     const float a = aa[(long long)img * c + ch], b = ab[(long long)img * c + ch];
     float mean = 0.f;
     for (int p = 0; p < hw; ++p) {
-      const float v = adm_silu(a * adm_bf16_to_f32(hsrc[((long long)img * hw + p) * c + ch]) + b);
+      const float v = adm_silu(a * adm_h_to_f32(hsrc[((long long)img * hw + p) * c + ch]) + b);
       mean += v;
-      tok[((long long)img * tpad + 1 + p) * c + ch] = adm_f32_to_bf16(v + pos[(long long)ch * T + 1 + p]);
+      tok[((long long)img * tpad + 1 + p) * c + ch] = adm_f32_to_h(v + pos[(long long)ch * T + 1 + p]);
     }
-    tok[((long long)img * tpad) * c + ch] = adm_f32_to_bf16(mean / (float)hw + pos[(long long)ch * T]);
+    tok[((long long)img * tpad) * c + ch] = adm_f32_to_h(mean / (float)hw + pos[(long long)ch * T]);
     for (int p = T; p < tpad; ++p) tok[((long long)img * tpad + p) * c + ch] = 0;
   }
 }
@@ -254,14 +254,14 @@ pool_attn_fwd_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ a0, f
   float* w = sh + d;
   const int hd = blockIdx.x, img = blockIdx.y, c = heads * d, c3 = 3 * c;
   const uint16_t* base = qkv + (long long)img * tpad * c3;
-  for (int j = threadIdx.x; j < d; j += 64) q0[j] = adm_bf16_to_f32(base[hd * d + j]);
+  for (int j = threadIdx.x; j < d; j += 64) q0[j] = adm_h_to_f32(base[hd * d + j]);
   __syncthreads();
   const float scale = rsqrtf((float)d);
   float mx = -3.0e38f;
   for (int s = threadIdx.x; s < T; s += 64) {
     const uint16_t* kr = base + (long long)s * c3 + c + hd * d;
     float acc = 0.f;
-    for (int j = 0; j < d; ++j) acc += q0[j] * adm_bf16_to_f32(kr[j]);
+    for (int j = 0; j < d; ++j) acc += q0[j] * adm_h_to_f32(kr[j]);
     acc *= scale;
     w[s] = acc;
     mx = fmaxf(mx, acc);
@@ -279,7 +279,7 @@ pool_attn_fwd_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ a0, f
   __syncthreads();
   for (int j = threadIdx.x; j < d; j += 64) {
     float acc = 0.f;
-    for (int s = 0; s < T; ++s) acc += w[s] * adm_bf16_to_f32(base[(long long)s * c3 + 2 * c + hd * d + j]);
+    for (int s = 0; s < T; ++s) acc += w[s] * adm_h_to_f32(base[(long long)s * c3 + 2 * c + hd * d + j]);
     a0[(long long)img * c + hd * d + j] = acc;
   }
 }
@@ -296,7 +296,7 @@ pool_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__
   const uint16_t* base = qkv + (long long)img * tpad * c3;
   uint16_t* obase = dqkv + (long long)img * tpad * c3;
   const float* w = wts + ((long long)img * heads + hd) * tpad;
-  for (int j = threadIdx.x; j < d; j += 64) { q0[j] = adm_bf16_to_f32(base[hd * d + j]); da[j] = da0[(long long)img * c + hd * d + j]; }
+  for (int j = threadIdx.x; j < d; j += 64) { q0[j] = adm_h_to_f32(base[hd * d + j]); da[j] = da0[(long long)img * c + hd * d + j]; }
   __syncthreads();
   const float scale = rsqrtf((float)d);
   const int d8 = d / 8;  // 16-byte segments per head row (d % 8 == 0)
@@ -309,7 +309,7 @@ pool_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        dw += da[j8 * 8 + 2 * e] * __uint_as_float(u[e] << 16) + da[j8 * 8 + 2 * e + 1] * __uint_as_float(u[e] & 0xffff0000u);
+        dw += da[j8 * 8 + 2 * e] * adm_lo_f32(u[e]) + da[j8 * 8 + 2 * e + 1] * adm_hi_f32(u[e]);
     }
     dlg[s] = dw;
     delta += w[s] * dw;
@@ -328,8 +328,8 @@ pool_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int j = j8 * 8 + 2 * e;
-        kk[e] = (uint32_t)adm_f32_to_bf16(dl * q0[j]) | ((uint32_t)adm_f32_to_bf16(dl * q0[j + 1]) << 16);
-        vv[e] = (uint32_t)adm_f32_to_bf16(ws * da[j]) | ((uint32_t)adm_f32_to_bf16(ws * da[j + 1]) << 16);
+        kk[e] = (uint32_t)adm_f32_to_h(dl * q0[j]) | ((uint32_t)adm_f32_to_h(dl * q0[j + 1]) << 16);
+        vv[e] = (uint32_t)adm_f32_to_h(ws * da[j]) | ((uint32_t)adm_f32_to_h(ws * da[j + 1]) << 16);
       }
     }
     *reinterpret_cast<uint4*>(orow + c) = make_uint4(kk[0], kk[1], kk[2], kk[3]);
@@ -338,8 +338,8 @@ pool_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__
   }
   for (int j = threadIdx.x; j < d; j += 64) {
     float acc = 0.f;
-    for (int s = 0; s < T; ++s) acc += dlg[s] * adm_bf16_to_f32(base[(long long)s * c3 + c + hd * d + j]);
-    obase[hd * d + j] = adm_f32_to_bf16(acc);
+    for (int s = 0; s < T; ++s) acc += dlg[s] * adm_h_to_f32(base[(long long)s * c3 + c + hd * d + j]);
+    obase[hd * d + j] = adm_f32_to_h(acc);
   }
 }
 
@@ -351,9 +351,9 @@ pool_prep_bwd_kernel(const uint16_t* __restrict__ dtok, uint16_t* __restrict__ d
     const int ch = (int)(it % c);
     const long long r = it / c;
     const int p = (int)(r % hw), img = (int)(r / hw);
-    const float v = adm_bf16_to_f32(dtok[((long long)img * tpad + 1 + p) * c + ch]) +
-                    adm_bf16_to_f32(dtok[((long long)img * tpad) * c + ch]) / (float)hw;
-    dact[it] = adm_f32_to_bf16(v);
+    const float v = adm_h_to_f32(dtok[((long long)img * tpad + 1 + p) * c + ch]) +
+                    adm_h_to_f32(dtok[((long long)img * tpad) * c + ch]) / (float)hw;
+    dact[it] = adm_f32_to_h(v);
   }
 }
 
@@ -372,7 +372,7 @@ pack_weight_bwd_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, 
     const int k = chunk * 32 + (ln >> 4) * 8 + e;  // input channel of the backward conv = co
     float v = 0.0f;
     if (ch < cin) v = w[((long long)k * cin + ch) * taps + (taps - 1 - tap)];
-    out[i] = adm_f32_to_bf16(v);
+    out[i] = adm_f32_to_h(v);
   }
 }
 

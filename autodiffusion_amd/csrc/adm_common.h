@@ -6,9 +6,23 @@
 
 #include "../../include/adm_hip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// The 16-bit element type of activations and weights.  Default build: bfloat16 (libadm_hip.so; BASELINE config 2 names bf16).
+// -DADM_ACT_F16 builds the SAME kernels for IEEE half (libadm_hip_f16.so): the reference's own torso type
+// (use_fp16=True, unet.py:618-624) -- 11 mantissa bits instead of 8, the matrix cores run both at one rate
+// (v_mfma_f32_16x16x32_f16 / _bf16), accumulation / GroupNorm / softmax / sampler stay fp32 in either.
+#ifdef ADM_ACT_F16
+typedef _Float16 adm_elem_t;
+#define ADM_ONE16 0x3C00
+#else
+typedef __bf16 adm_elem_t;
+#define ADM_ONE16 0x3F80
+#endif
+typedef __attribute__((ext_vector_type(8))) adm_elem_t adm_h8;
+typedef __attribute__((ext_vector_type(4))) adm_elem_t adm_h4;
+typedef __attribute__((ext_vector_type(2))) adm_elem_t adm_h2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float adm_f32x16;
+typedef __attribute__((ext_vector_type(4))) short adm_s16x4_t;
 
 // thread-local error text, set by ADM_FAIL / adm_check_launch
 void adm_set_error(const char* fmt, ...);
@@ -35,12 +49,42 @@ static inline int adm_check_launch(const char* what) {
 
 static inline bool adm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
-__device__ __forceinline__ float adm_bf16_to_f32(uint16_t v) {
-  return __uint_as_float(((uint32_t)v) << 16);
-}
-__device__ __forceinline__ uint16_t adm_f32_to_bf16(float f) {
+// element <-> fp32 (the raw 16-bit pattern travels as uint16_t / packed pairs in uint32_t)
+#ifdef ADM_ACT_F16
+__device__ __forceinline__ float adm_h_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t adm_f32_to_h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }  // round-to-nearest-even
+__device__ __forceinline__ float adm_lo_f32(uint32_t u) { return (float)__builtin_bit_cast(adm_h2, u)[0]; }
+__device__ __forceinline__ float adm_hi_f32(uint32_t u) { return (float)__builtin_bit_cast(adm_h2, u)[1]; }  // v_cvt_f32_f16 ... WORD_1
+#else
+__device__ __forceinline__ float adm_h_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t adm_f32_to_h(float f) {
   __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
   return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float adm_lo_f32(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float adm_hi_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
+// the matrix-core products of the element type (A, B fragments as adm_h8 / 4 x 16 bits; fp32 accumulators)
+__device__ __forceinline__ f32x4 adm_mfma_16x16x32(adm_h8 a, adm_h8 b, f32x4 c, int, int, int) {
+#ifdef ADM_ACT_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ adm_f32x16 adm_mfma_32x32x16(adm_h8 a, adm_h8 b, adm_f32x16 c, int, int, int) {
+#ifdef ADM_ACT_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 adm_mfma_16x16x16(adm_s16x4_t a, adm_s16x4_t b, f32x4 c, int, int, int) {
+#ifdef ADM_ACT_F16
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(adm_h4, a), __builtin_bit_cast(adm_h4, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ float adm_silu(float v) {
   // v * sigmoid(v) = v * rcp(1 + 2^(-v*log2 e)): v_exp_f32 + v_rcp_f32 (1 ulp each), 5 VALU ops -- a full

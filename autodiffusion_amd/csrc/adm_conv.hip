@@ -348,10 +348,10 @@ conv_kernel(const ConvK p) {
       const bool valid = pixrel[ps] >= 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        adm_f32x2_t t = {__uint_as_float(u[j] << 16), __uint_as_float(u[j] & 0xffff0000u)};
+        adm_f32x2_t t = {adm_lo_f32(u[j]), adm_hi_f32(u[j])};
         t = __builtin_elementwise_fma(adm_f32x2_t{a8[2 * j], a8[2 * j + 1]}, t, adm_f32x2_t{b8[2 * j], b8[2 * j + 1]});
         if constexpr (PRO == 2) t = adm_silu2(t);
-        const uint32_t pk = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+        const uint32_t pk = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
         u[j] = valid ? pk : 0u;
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
@@ -370,15 +370,15 @@ conv_kernel(const ConvK p) {
     // scheduling fence: the staging work issued above (loads, prologue transform, LDS writes and their
     // own LDS reads) stays out of the pinned read/MFMA pipeline below
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 af[TM];
+    adm_h8 af[TM];
 #pragma unroll
-    for (int i = 0; i < AFD; ++i) af[i] = *reinterpret_cast<const bf16x8*>(hl + aoff[i]);
+    for (int i = 0; i < AFD; ++i) af[i] = *reinterpret_cast<const adm_h8*>(hl + aoff[i]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (i + AFD < TM) af[i + AFD] = *reinterpret_cast<const bf16x8*>(hl + aoff[i + AFD]);
+      if (i + AFD < TM) af[i + AFD] = *reinterpret_cast<const adm_h8*>(hl + aoff[i + AFD]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = adm_mfma_16x16x32(__builtin_bit_cast(adm_h8, w[j]), af[i], acc[i][j], 0, 0, 0);
     }
     // pin the interleave in the emitted code: AFD reads up front, then {1 read, TN MFMAs} per pixel tile
     // (LLVM otherwise sinks every read next to its use to save registers)
@@ -627,8 +627,8 @@ conv_kernel(const ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           uint2 o;
-          o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1]) << 16);
-          o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3]) << 16);
+          o.x = (uint32_t)adm_f32_to_h(acc[i][j][0]) | ((uint32_t)adm_f32_to_h(acc[i][j][1]) << 16);
+          o.y = (uint32_t)adm_f32_to_h(acc[i][j][2]) | ((uint32_t)adm_f32_to_h(acc[i][j][3]) << 16);
           *reinterpret_cast<uint2*>(stg + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
         }
       }
@@ -691,9 +691,9 @@ conv_kernel(const ConvK p) {
             const uint32_t r4[4] = {rr[g][k].x, rr[g][k].y, rr[g][k].z, rr[g][k].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)} +
-                              f32x2{__uint_as_float(r4[q] << 16), __uint_as_float(r4[q] & 0xffff0000u)};
-              a4[q] = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+              const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])} +
+                              f32x2{adm_lo_f32(r4[q]), adm_hi_f32(r4[q])};
+              a4[q] = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
             }
             v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
           }
@@ -703,7 +703,7 @@ conv_kernel(const ConvK p) {
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)};
+            const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])};
             s1[g][q] += t;
             s2[g][q] = __builtin_elementwise_fma(t, t, s2[g][q]);
           }
@@ -900,11 +900,11 @@ conv32_kernel(const ConvK p) {
       const bool valid = pixrel[ps] >= 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+        float lo = adm_lo_f32(u[j]), hi = adm_hi_f32(u[j]);
         lo = a8[2 * j] * lo + b8[2 * j];
         hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
         if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-        const uint32_t pk = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+        const uint32_t pk = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
         u[j] = valid ? pk : 0u;
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
@@ -923,10 +923,10 @@ conv32_kernel(const ConvK p) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(hl + aoff[i] + ks * 32);
+        const adm_h8 af = *reinterpret_cast<const adm_h8*>(hl + aoff[i] + ks * 32);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[j][ks]), af, acc[i][j], 0, 0, 0);
+          acc[i][j] = adm_mfma_32x32x16(__builtin_bit_cast(adm_h8, w[j][ks]), af, acc[i][j], 0, 0, 0);
       }
   };
 
@@ -986,8 +986,8 @@ conv32_kernel(const ConvK p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             uint2 o;
-            o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 0] + bs.x) | ((uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 1] + bs.y) << 16);
-            o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 2] + bs.z) | ((uint32_t)adm_f32_to_bf16(acc[i][j][4 * g + 3] + bs.w) << 16);
+            o.x = (uint32_t)adm_f32_to_h(acc[i][j][4 * g + 0] + bs.x) | ((uint32_t)adm_f32_to_h(acc[i][j][4 * g + 1] + bs.y) << 16);
+            o.y = (uint32_t)adm_f32_to_h(acc[i][j][4 * g + 2] + bs.z) | ((uint32_t)adm_f32_to_h(acc[i][j][4 * g + 3] + bs.w) << 16);
             *reinterpret_cast<uint2*>(smem + (i * 32 + lp) * EROW + ch0 * 2) = o;
           }
         }
@@ -1006,9 +1006,9 @@ conv32_kernel(const ConvK p) {
         const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float lo = __uint_as_float(a4[q] << 16) + __uint_as_float(r4[q] << 16);
-          const float hi = __uint_as_float(a4[q] & 0xffff0000u) + __uint_as_float(r4[q] & 0xffff0000u);
-          a4[q] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+          const float lo = adm_lo_f32(a4[q]) + adm_lo_f32(r4[q]);
+          const float hi = adm_hi_f32(a4[q]) + adm_hi_f32(r4[q]);
+          a4[q] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
         }
         v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
       }
@@ -1032,7 +1032,7 @@ pack_weight32_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, in
     const int k = chunk * KC + ks * 16 + (ln >> 5) * 8 + e;
     float v = 0.0f;
     if (ch < cout) v = w[((long long)ch * cin + k) * taps + tap];
-    out[i] = adm_f32_to_bf16(v);
+    out[i] = adm_f32_to_h(v);
   }
 }
 
@@ -1071,7 +1071,7 @@ pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int 
     const int k = chunk * KC + (ln >> 4) * 8 + e;
     float v = 0.0f;
     if (ch < cout) v = w[((long long)ch * cin + k) * taps + tap];
-    out[i] = adm_f32_to_bf16(v);
+    out[i] = adm_f32_to_h(v);
   }
 }
 
@@ -1107,21 +1107,21 @@ conv_splitk_reduce(const float* __restrict__ ws, int ksplit, const float* __rest
       }
       uint32_t o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (uint32_t)adm_f32_to_bf16(v[2 * j]) | ((uint32_t)adm_f32_to_bf16(v[2 * j + 1]) << 16);
+      for (int j = 0; j < 4; ++j) o[j] = (uint32_t)adm_f32_to_h(v[2 * j]) | ((uint32_t)adm_f32_to_h(v[2 * j + 1]) << 16);
       if (res) {   // as the one-pass epilogue: the conv result is rounded to bf16 first, then the residual is added
         const uint4 rv = *reinterpret_cast<const uint4*>(res + e);
         const uint32_t r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float lo = __uint_as_float(o[j] << 16) + __uint_as_float(r4[j] << 16);
-          const float hi = __uint_as_float(o[j] & 0xffff0000u) + __uint_as_float(r4[j] & 0xffff0000u);
-          o[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+          const float lo = adm_lo_f32(o[j]) + adm_lo_f32(r4[j]);
+          const float hi = adm_hi_f32(o[j]) + adm_hi_f32(r4[j]);
+          o[j] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
         }
       }
       *reinterpret_cast<uint4*>(out + e) = make_uint4(o[0], o[1], o[2], o[3]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float lo = __uint_as_float(o[j] << 16), hi = __uint_as_float(o[j] & 0xffff0000u);
+        const float lo = adm_lo_f32(o[j]), hi = adm_hi_f32(o[j]);
         t1[2 * j] += lo; t2[2 * j] += lo * lo; t1[2 * j + 1] += hi; t2[2 * j + 1] += hi * hi;
       }
     }

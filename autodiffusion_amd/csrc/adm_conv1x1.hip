@@ -125,11 +125,11 @@ conv1x1r_kernel(const Conv1K p) {
           uint32_t w4[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float lo = __uint_as_float(w4[j] << 16), hi = __uint_as_float(w4[j] & 0xffff0000u);
+            float lo = adm_lo_f32(w4[j]), hi = adm_hi_f32(w4[j]);
             lo = a8[2 * j] * lo + b8[2 * j];
             hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
             if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-            w4[j] = (uint32_t)adm_f32_to_bf16(lo) | ((uint32_t)adm_f32_to_bf16(hi) << 16);
+            w4[j] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
           }
           o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
@@ -163,15 +163,15 @@ conv1x1r_kernel(const Conv1K p) {
         constexpr int AFD = TM < 4 ? TM : 4;
         const unsigned char* ak = alane + ks * 64;
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 af[TM];
+        adm_h8 af[TM];
 #pragma unroll
-        for (int i = 0; i < AFD; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ak + i * 16 * RB);
+        for (int i = 0; i < AFD; ++i) af[i] = *reinterpret_cast<const adm_h8*>(ak + i * 16 * RB);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          if (i + AFD < TM) af[i + AFD] = *reinterpret_cast<const bf16x8*>(ak + (i + AFD) * 16 * RB);
+          if (i + AFD < TM) af[i + AFD] = *reinterpret_cast<const adm_h8*>(ak + (i + AFD) * 16 * RB);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]), af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = adm_mfma_16x16x32(__builtin_bit_cast(adm_h8, w[j]), af[i], acc[i][j], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < AFD; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -220,8 +220,8 @@ conv1x1r_kernel(const Conv1K p) {
             for (int j = 0; j < TN; ++j) {
               const f32x4 v = acc[2 * c + ii][j];
               uint2 o;
-              o.x = (uint32_t)adm_f32_to_bf16(v[0]) | ((uint32_t)adm_f32_to_bf16(v[1]) << 16);
-              o.y = (uint32_t)adm_f32_to_bf16(v[2]) | ((uint32_t)adm_f32_to_bf16(v[3]) << 16);
+              o.x = (uint32_t)adm_f32_to_h(v[0]) | ((uint32_t)adm_f32_to_h(v[1]) << 16);
+              o.y = (uint32_t)adm_f32_to_h(v[2]) | ((uint32_t)adm_f32_to_h(v[3]) << 16);
               *reinterpret_cast<uint2*>(wst + (ii * 16 + lc) * WROW + (j * 16 + lq * 4) * 2) = o;
             }
 #pragma unroll
@@ -236,16 +236,16 @@ conv1x1r_kernel(const Conv1K p) {
               const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const f32x2 t = f32x2{__uint_as_float(a4[e] << 16), __uint_as_float(a4[e] & 0xffff0000u)} +
-                                f32x2{__uint_as_float(r4[e] << 16), __uint_as_float(r4[e] & 0xffff0000u)};
-                a4[e] = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+                const f32x2 t = f32x2{adm_lo_f32(a4[e]), adm_hi_f32(a4[e])} +
+                                f32x2{adm_lo_f32(r4[e]), adm_hi_f32(r4[e])};
+                a4[e] = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
               }
               v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
             }
             *reinterpret_cast<uint4*>(p.out + eo) = v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const f32x2 t = f32x2{__uint_as_float(a4[e] << 16), __uint_as_float(a4[e] & 0xffff0000u)};
+              const f32x2 t = f32x2{adm_lo_f32(a4[e]), adm_hi_f32(a4[e])};
               s1[e] += t;
               s2[e] = __builtin_elementwise_fma(t, t, s2[e]);
             }
@@ -287,8 +287,8 @@ conv1x1r_kernel(const Conv1K p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
               uint2 o;
-              o.x = (uint32_t)adm_f32_to_bf16(acc[i][j][0]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][1]) << 16);
-              o.y = (uint32_t)adm_f32_to_bf16(acc[i][j][2]) | ((uint32_t)adm_f32_to_bf16(acc[i][j][3]) << 16);
+              o.x = (uint32_t)adm_f32_to_h(acc[i][j][0]) | ((uint32_t)adm_f32_to_h(acc[i][j][1]) << 16);
+              o.y = (uint32_t)adm_f32_to_h(acc[i][j][2]) | ((uint32_t)adm_f32_to_h(acc[i][j][3]) << 16);
               *reinterpret_cast<uint2*>(stg + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
             }
           }
@@ -316,16 +316,16 @@ conv1x1r_kernel(const Conv1K p) {
             const uint32_t r4[4] = {rr[k].x, rr[k].y, rr[k].z, rr[k].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)} +
-                              f32x2{__uint_as_float(r4[q] << 16), __uint_as_float(r4[q] & 0xffff0000u)};
-              a4[q] = (uint32_t)adm_f32_to_bf16(t.x) | ((uint32_t)adm_f32_to_bf16(t.y) << 16);
+              const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])} +
+                              f32x2{adm_lo_f32(r4[q]), adm_hi_f32(r4[q])};
+              a4[q] = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
             }
             v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
           }
           *reinterpret_cast<uint4*>(p.out + ((long long)pb + m) * p.Cout + gch) = v;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x2 t = f32x2{__uint_as_float(a4[q] << 16), __uint_as_float(a4[q] & 0xffff0000u)};
+            const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])};
             s1[q] += t;
             s2[q] = __builtin_elementwise_fma(t, t, s2[q]);
           }

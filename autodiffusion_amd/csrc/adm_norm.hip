@@ -51,10 +51,10 @@ stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const floa
       }
     }
     uint4 pk;
-    pk.x = adm_f32_to_bf16(acc[0]) | ((uint32_t)adm_f32_to_bf16(acc[1]) << 16);
-    pk.y = adm_f32_to_bf16(acc[2]) | ((uint32_t)adm_f32_to_bf16(acc[3]) << 16);
-    pk.z = adm_f32_to_bf16(acc[4]) | ((uint32_t)adm_f32_to_bf16(acc[5]) << 16);
-    pk.w = adm_f32_to_bf16(acc[6]) | ((uint32_t)adm_f32_to_bf16(acc[7]) << 16);
+    pk.x = adm_f32_to_h(acc[0]) | ((uint32_t)adm_f32_to_h(acc[1]) << 16);
+    pk.y = adm_f32_to_h(acc[2]) | ((uint32_t)adm_f32_to_h(acc[3]) << 16);
+    pk.z = adm_f32_to_h(acc[4]) | ((uint32_t)adm_f32_to_h(acc[5]) << 16);
+    pk.w = adm_f32_to_h(acc[6]) | ((uint32_t)adm_f32_to_h(acc[7]) << 16);
     *reinterpret_cast<uint4*>(out + pix * cout + g * 8) = pk;
   }
 }
@@ -74,7 +74,7 @@ nchw_to_nhwc_pad_kernel(const float* __restrict__ x, uint16_t* __restrict__ out,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int ch = g * 8 + j;
-      if (ch < c) u[j >> 1] |= (uint32_t)adm_f32_to_bf16(x[((long long)img * c + ch) * hw + p]) << ((j & 1) * 16);
+      if (ch < c) u[j >> 1] |= (uint32_t)adm_f32_to_h(x[((long long)img * c + ch) * hw + p]) << ((j & 1) * 16);
     }
     *reinterpret_cast<uint4*>(out + pix * cpad + g * 8) = make_uint4(u[0], u[1], u[2], u[3]);
   }
@@ -106,7 +106,7 @@ gn_partial_kernel(const uint16_t* __restrict__ in0, int c0, const uint16_t* __re
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = __uint_as_float(u[j] << 16), b = __uint_as_float(u[j] & 0xffff0000u);
+        const float a = adm_lo_f32(u[j]), b = adm_hi_f32(u[j]);
         s[2 * j] += a; ss[2 * j] += a * a;
         s[2 * j + 1] += b; ss[2 * j + 1] += b * b;
       }
@@ -233,7 +233,7 @@ resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+        float lo = adm_lo_f32(u[j]), hi = adm_hi_f32(u[j]);
         if (ACT) {
           lo = adm_silu(a8[2 * j] * lo + b8[2 * j]);
           hi = adm_silu(a8[2 * j + 1] * hi + b8[2 * j + 1]);
@@ -247,10 +247,10 @@ resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a
       for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
     }
     uint4 pk;
-    pk.x = adm_f32_to_bf16(acc[0]) | ((uint32_t)adm_f32_to_bf16(acc[1]) << 16);
-    pk.y = adm_f32_to_bf16(acc[2]) | ((uint32_t)adm_f32_to_bf16(acc[3]) << 16);
-    pk.z = adm_f32_to_bf16(acc[4]) | ((uint32_t)adm_f32_to_bf16(acc[5]) << 16);
-    pk.w = adm_f32_to_bf16(acc[6]) | ((uint32_t)adm_f32_to_bf16(acc[7]) << 16);
+    pk.x = adm_f32_to_h(acc[0]) | ((uint32_t)adm_f32_to_h(acc[1]) << 16);
+    pk.y = adm_f32_to_h(acc[2]) | ((uint32_t)adm_f32_to_h(acc[3]) << 16);
+    pk.z = adm_f32_to_h(acc[4]) | ((uint32_t)adm_f32_to_h(acc[5]) << 16);
+    pk.w = adm_f32_to_h(acc[6]) | ((uint32_t)adm_f32_to_h(acc[7]) << 16);
     *reinterpret_cast<uint4*>(out + opix * c + g * 8) = pk;
   }
 }

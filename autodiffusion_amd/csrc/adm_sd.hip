@@ -16,17 +16,17 @@ __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
   const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    f[2 * j] = __uint_as_float(u[j] << 16);
-    f[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u);
+    f[2 * j] = adm_lo_f32(u[j]);
+    f[2 * j + 1] = adm_hi_f32(u[j]);
   }
 }
 
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 pk;
-  pk.x = adm_f32_to_bf16(f[0]) | ((uint32_t)adm_f32_to_bf16(f[1]) << 16);
-  pk.y = adm_f32_to_bf16(f[2]) | ((uint32_t)adm_f32_to_bf16(f[3]) << 16);
-  pk.z = adm_f32_to_bf16(f[4]) | ((uint32_t)adm_f32_to_bf16(f[5]) << 16);
-  pk.w = adm_f32_to_bf16(f[6]) | ((uint32_t)adm_f32_to_bf16(f[7]) << 16);
+  pk.x = adm_f32_to_h(f[0]) | ((uint32_t)adm_f32_to_h(f[1]) << 16);
+  pk.y = adm_f32_to_h(f[2]) | ((uint32_t)adm_f32_to_h(f[3]) << 16);
+  pk.z = adm_f32_to_h(f[4]) | ((uint32_t)adm_f32_to_h(f[5]) << 16);
+  pk.w = adm_f32_to_h(f[6]) | ((uint32_t)adm_f32_to_h(f[7]) << 16);
   return pk;
 }
 

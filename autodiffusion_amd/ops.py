@@ -16,6 +16,16 @@ from . import _lib
 from ._lib import AdmError, ConvArgs, StepCoefs, check
 
 BF16 = torch.bfloat16
+F16 = torch.float16   # the reference's torso type (use_fp16=True): libadm_hip_f16.so, same kernels built for IEEE half
+
+
+def _L(t):
+    """The library built for tensor t's 16-bit element type (bf16: libadm_hip.so, fp16: libadm_hip_f16.so)."""
+    if t.dtype == BF16:
+        return _lib.load()
+    if t.dtype == F16:
+        return _lib.load("f16")
+    raise AdmError(f"expected a bfloat16 or float16 activation tensor, got {t.dtype}")
 GN_EPS = 1e-5
 
 # conv epilogues accumulate the GroupNorm partial sums of their output (consumed by gn_affine)
@@ -100,21 +110,21 @@ def linear_f32(x, w, b=None, silu_in=False, table=None, idx=None, out=None):
 
 
 # ------------------------------------------------------------------ stem / norm / resample
-def stem_conv3x3(x_nchw, w, b):
+def stem_conv3x3(x_nchw, w, b, dtype=BF16):
     n, cin, h, wd = x_nchw.shape
     cout = w.shape[0]
-    out = torch.empty((n, h, wd, cout), dtype=BF16, device=x_nchw.device)
-    check(_lib.load().adm_stem_conv3x3(_ptr(x_nchw, torch.float32, "x"), _ptr(w, torch.float32, "w"),
+    out = torch.empty((n, h, wd, cout), dtype=dtype, device=x_nchw.device)
+    check(_L(out).adm_stem_conv3x3(_ptr(x_nchw, torch.float32, "x"), _ptr(w, torch.float32, "w"),
                                        _ptr(b, torch.float32, "b"), _ptr(out), n, cin, h, wd, cout, _stream()),
           "adm_stem_conv3x3")
     return out
 
 
-def nchw_to_nhwc_pad(x_nchw, cpad: int = 32):
+def nchw_to_nhwc_pad(x_nchw, cpad: int = 32, dtype=BF16):
     """fp32 NCHW image -> bf16 NHWC with channels zero-padded to cpad (input of the MFMA stem conv)."""
     n, c, h, w = x_nchw.shape
-    out = torch.empty((n, h, w, cpad), dtype=BF16, device=x_nchw.device)
-    check(_lib.load().adm_nchw_to_nhwc_pad(_ptr(x_nchw, torch.float32, "x"), _ptr(out), n, c, h, w, cpad, _stream()),
+    out = torch.empty((n, h, w, cpad), dtype=dtype, device=x_nchw.device)
+    check(_L(out).adm_nchw_to_nhwc_pad(_ptr(x_nchw, torch.float32, "x"), _ptr(out), n, c, h, w, cpad, _stream()),
           "adm_nchw_to_nhwc_pad")
     return out
 
@@ -135,7 +145,7 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
     n, h, w, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     c, hw = c0 + c1, h * w
-    lib = _lib.load()
+    lib = _L(x0)
     a = torch.empty((n, c), dtype=torch.float32, device=x0.device)
     b = torch.empty((n, c), dtype=torch.float32, device=x0.device)
     film_ptr = None
@@ -156,7 +166,7 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
         else:
             slabs = gn_slabs(hw)
             part = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
-            check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, None, 0, _ptr(part), n, hw, slabs, _stream()), "adm_gn_partial")
+            check(lib.adm_gn_partial(_ptr(x0, x0.dtype, "x0"), c0, None, 0, _ptr(part), n, hw, slabs, _stream()), "adm_gn_partial")
         check(lib.adm_gn_finalize_add(_ptr(part), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
                                       add.data_ptr(), add.stride(0), _ptr(a), _ptr(b), n, c, hw, slabs, eps, _stream()),
               "adm_gn_finalize_add")
@@ -171,7 +181,7 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
         slabs = gn_slabs(hw)
         if partial is None:
             partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
-        check(lib.adm_gn_partial(_ptr(x0, BF16, "x0"), c0, _ptr(x1, BF16, "x1"), c1, _ptr(partial), n, hw, slabs,
+        check(lib.adm_gn_partial(_ptr(x0, x0.dtype, "x0"), c0, _ptr(x1, x0.dtype, "x1"), c1, _ptr(partial), n, hw, slabs,
                                  _stream()), "adm_gn_partial")
         check(lib.adm_gn_finalize(_ptr(partial), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
                                   film_ptr, film_stride, _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, eps,
@@ -187,42 +197,42 @@ def resample(x, mode: str, aff=None):
     n, h, w, c = x.shape
     m = {"down": 1, "up": 2, "stride2": 3}[mode]
     oh, ow = (h * 2, w * 2) if m == 2 else (h // 2, w // 2)
-    out = torch.empty((n, oh, ow, c), dtype=BF16, device=x.device)
+    out = torch.empty((n, oh, ow, c), dtype=x.dtype, device=x.device)
     a, b = aff if aff is not None else (None, None)
-    check(_lib.load().adm_resample(_ptr(x, BF16, "x"), _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(out),
+    check(_L(x).adm_resample(_ptr(x, x.dtype, "x"), _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(out),
                                    n, h, w, c, m, _stream()), "adm_resample")
     return out
 
 
 # ------------------------------------------------------------------ conv / GEMM
-def pack_conv_weight(w):
+def pack_conv_weight(w, dtype=BF16):
     """fp32 [cout, cin, kh, kw] or [cout, cin, 1] or [cout, cin] -> packed bf16 image (1-D tensor)."""
     cout, cin = w.shape[0], w.shape[1]
     taps = 1
     for s in w.shape[2:]:
         taps *= s
-    lib = _lib.load()
+    lib = _lib.load("f16" if dtype == F16 else "bf16")
     elems = lib.adm_packed_weight_elems(cout, cin, taps)
     if elems < 0:
         raise AdmError(f"pack_conv_weight: unsupported weight shape {tuple(w.shape)} (cin % 32 == 0, taps 1|9)")
     w32 = w.detach().to(torch.float32).contiguous()
-    out = torch.empty((elems,), dtype=BF16, device=w.device)
+    out = torch.empty((elems,), dtype=dtype, device=w.device)
     check(lib.adm_pack_conv_weight(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight")
     return out
 
 
-def pack_conv_weight32(w):
+def pack_conv_weight32(w, dtype=BF16):
     """Same weight in the 32x32x16 fragment order (enables adm_conv's variant 7)."""
     cout, cin = w.shape[0], w.shape[1]
     taps = 1
     for s in w.shape[2:]:
         taps *= s
-    lib = _lib.load()
+    lib = _lib.load("f16" if dtype == F16 else "bf16")
     elems = lib.adm_packed_weight32_elems(cout, cin, taps)
     if elems < 0:
         raise AdmError(f"pack_conv_weight32: unsupported weight shape {tuple(w.shape)}")
     w32 = w.detach().to(torch.float32).contiguous()
-    out = torch.empty((elems,), dtype=BF16, device=w.device)
+    out = torch.empty((elems,), dtype=dtype, device=w.device)
     check(lib.adm_pack_conv_weight32(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight32")
     return out
 
@@ -254,19 +264,20 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     dev = x0.device
     if out is None:
         out = (torch.empty((n, cout, h, w), dtype=torch.float32, device=dev) if out_f32_nchw
-               else torch.empty((n, h, w, cout), dtype=BF16, device=dev))
+               else torch.empty((n, h, w, cout), dtype=x0.dtype, device=dev))
     a = ConvArgs()
-    a.in0, a.in1 = _ptr(x0, BF16, "x0"), _ptr(x1, BF16, "x1")
-    a.w_packed, a.bias = _ptr(w_packed, BF16, "w_packed"), _ptr(bias, torch.float32, "bias")
+    lib = _L(x0)
+    a.in0, a.in1 = _ptr(x0, x0.dtype, "x0"), _ptr(x1, x0.dtype, "x1")
+    a.w_packed, a.bias = _ptr(w_packed, x0.dtype, "w_packed"), _ptr(bias, torch.float32, "bias")
     if aff is not None:
         a.aff_a, a.aff_b = _ptr(aff[0], torch.float32, "aff_a"), _ptr(aff[1], torch.float32, "aff_b")
         a.prologue = 2 if silu else 1
     else:
         a.prologue = 0
-    a.res = _ptr(res, BF16, "res")
+    a.res = _ptr(res, x0.dtype, "res")
     a.out = _ptr(out)
     a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, c1, cout
-    a.w_packed32 = _ptr(w_packed32, BF16, "w_packed32")
+    a.w_packed32 = _ptr(w_packed32, x0.dtype, "w_packed32")
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     a.in_up, a.res_up = int(in_up), int(res_up)
     ws = None
@@ -278,13 +289,13 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     if in_up or res_up:
         w_packed32 = None  # the 32x32x16 kernel does not take the virtual upsample
     if variant == 0:
-        variant = _lib.load().adm_conv_pick_variant(C.byref(a))  # the library's own rule (incl. the resident-tile 1x1 kernel)
+        variant = lib.adm_conv_pick_variant(C.byref(a))  # the library's own rule (incl. the resident-tile 1x1 kernel)
         if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw:
             variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
         a.variant = variant
     fused = None
     if want_stats and USE_FUSED_STATS:
-        slabs = _lib.load().adm_conv_stat_slabs(C.byref(a))
+        slabs = lib.adm_conv_stat_slabs(C.byref(a))
         if slabs > 0:
             fused = (torch.empty((n, slabs, cout, 2), dtype=torch.float32, device=dev), slabs)
             a.out_stats = fused[0].data_ptr()
@@ -292,12 +303,12 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     if CONV_PROFILE is not None and (CONV_PROFILE_KEY is None or CONV_PROFILE_KEY == (variant, taps, h * w > 64, a.prologue)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
+        check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
         e1.record()
         CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64, a.prologue),
                              (n, h, w, c0 + c1, cout)))
         return out
-    check(_lib.load().adm_conv(C.byref(a), _stream()), "adm_conv")
+    check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
     return out
 
 
@@ -307,9 +318,9 @@ def attention(qkv, heads: int, new_order: bool, want_lse: bool = False):
     n, t, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
-    out = torch.empty((n, t, c), dtype=BF16, device=qkv.device)
+    out = torch.empty((n, t, c), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((n, heads, t), dtype=torch.float32, device=qkv.device) if want_lse else None
-    check(_lib.load().adm_attention_lse(_ptr(qkv, BF16, "qkv"), _ptr(out), _ptr(lse), n, t, heads, d,
+    check(_L(qkv).adm_attention_lse(_ptr(qkv, qkv.dtype, "qkv"), _ptr(out), _ptr(lse), n, t, heads, d,
                                         int(new_order), _stream()), "adm_attention")
     return (out, lse) if want_lse else out
 
@@ -321,11 +332,11 @@ def attention_cross(q, kv, heads: int, d: int, tk: int, scale: float, q_cols: in
     n, tq, _ = q.shape
     if q.stride(2) != 1 or kv.stride(2) != 1 or q.stride(0) != tq * q.stride(1) or kv.stride(0) != kv.shape[1] * kv.stride(1):
         raise AdmError("attention_cross: q / kv must be row-major with dense image pitch")
-    out = torch.empty((n, tq, heads * d), dtype=BF16, device=q.device)
+    out = torch.empty((n, tq, heads * d), dtype=q.dtype, device=q.device)
     for t_ in (q, kv):
-        if t_.dtype != BF16 or not t_.is_cuda:
-            raise AdmError("attention_cross: bf16 device tensors required")
-    check(_lib.load().adm_attention_cross(q.data_ptr(), q.stride(1), kv.data_ptr(), kv.stride(1), kv.shape[1],
+        if t_.dtype != q.dtype or not t_.is_cuda:
+            raise AdmError("attention_cross: q and kv must be device tensors of one 16-bit type")
+    check(_L(q).adm_attention_cross(q.data_ptr(), q.stride(1), kv.data_ptr(), kv.stride(1), kv.shape[1],
                                           _ptr(out), n, tq, tk, heads, d, float(scale), _stream()), "adm_attention_cross")
     return out
 
@@ -335,7 +346,7 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
     """bf16 [..., C] -> bf16, LayerNorm over the last dimension (fp32 statistics)."""
     c = x.shape[-1]
     out = torch.empty_like(x)
-    check(_lib.load().adm_layernorm(_ptr(x, BF16, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+    check(_L(x).adm_layernorm(_ptr(x, x.dtype, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
                                     _ptr(out), x.numel() // c, c, float(eps), _stream()), "adm_layernorm")
     return out
 
@@ -343,8 +354,8 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
 def geglu(u):
     """bf16 [..., 2*I] -> bf16 [..., I]: u[..., :I] * gelu(u[..., I:])."""
     inner = u.shape[-1] // 2
-    out = torch.empty(u.shape[:-1] + (inner,), dtype=BF16, device=u.device)
-    check(_lib.load().adm_geglu(_ptr(u, BF16, "u"), _ptr(out), u.numel() // (2 * inner), inner, _stream()), "adm_geglu")
+    out = torch.empty(u.shape[:-1] + (inner,), dtype=u.dtype, device=u.device)
+    check(_L(u).adm_geglu(_ptr(u, u.dtype, "u"), _ptr(out), u.numel() // (2 * inner), inner, _stream()), "adm_geglu")
     return out
 
 
@@ -354,7 +365,7 @@ def attention_bwd(qkv, out, dout, lse, heads: int, new_order: bool):
     d = c3 // 3 // heads
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((n, heads, t), dtype=torch.float32, device=qkv.device)
-    check(_lib.load().adm_attention_bwd(_ptr(qkv, BF16, "qkv"), _ptr(out, BF16, "out"), _ptr(dout, BF16, "dout"),
+    check(_L(qkv).adm_attention_bwd(_ptr(qkv, qkv.dtype, "qkv"), _ptr(out, qkv.dtype, "out"), _ptr(dout, qkv.dtype, "dout"),
                                         _ptr(lse, torch.float32, "lse"), _ptr(delta), _ptr(dqkv), n, t, heads, d,
                                         int(new_order), _stream()), "adm_attention_bwd")
     return dqkv
@@ -364,19 +375,19 @@ def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=Fals
     """Backward of y = act(a*x+b) (GroupNorm(+FiLM)(+SiLU)): returns dx bf16 NHWC (+ add)."""
     n, h, w, c = x.shape
     hw = h * w
-    lib = _lib.load()
+    lib = _L(x)
     slabs = gn_slabs(hw)
     partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x.device)
     k1 = torch.empty((n, c), dtype=torch.float32, device=x.device)
     k0 = torch.empty((n, c), dtype=torch.float32, device=x.device)
     a, b = aff
-    check(lib.adm_gn_bwd_partial(_ptr(x, BF16, "x"), _ptr(dy, BF16, "dy"), _ptr(a, torch.float32), _ptr(b, torch.float32),
+    check(lib.adm_gn_bwd_partial(_ptr(x, x.dtype, "x"), _ptr(dy, x.dtype, "dy"), _ptr(a, torch.float32), _ptr(b, torch.float32),
                                  _ptr(partial), n, h, w, c, slabs, int(silu), int(dy_half), _stream()),
           "adm_gn_bwd_partial")
     check(lib.adm_gn_bwd_finalize(_ptr(partial), _ptr(a), _ptr(stats, torch.float32, "stats"), _ptr(k1), _ptr(k0),
                                   n, c, hw, slabs, _stream()), "adm_gn_bwd_finalize")
     out = torch.empty_like(x)
-    check(lib.adm_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(a), _ptr(b), _ptr(k1), _ptr(k0), _ptr(add, BF16, "add"),
+    check(lib.adm_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(a), _ptr(b), _ptr(k1), _ptr(k0), _ptr(add, x.dtype, "add"),
                                _ptr(out), n, h, w, c, int(silu), int(dy_half), int(add_half), _stream()),
           "adm_gn_bwd_apply")
     return out
@@ -385,7 +396,7 @@ def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=Fals
 def grad_add(a, b, b_half=False):
     n, h, w, c = a.shape
     out = torch.empty_like(a)
-    check(_lib.load().adm_grad_add(_ptr(a, BF16, "a"), _ptr(b, BF16, "b"), _ptr(out), n, h, w, c, int(b_half),
+    check(_L(a).adm_grad_add(_ptr(a, a.dtype, "a"), _ptr(b, a.dtype, "b"), _ptr(out), n, h, w, c, int(b_half),
                                    _stream()), "adm_grad_add")
     return out
 
@@ -400,8 +411,8 @@ def logsoftmax_grad(logits, y, scale: float):
 
 def pool_prep(h, aff, pos, tpad: int):
     n, hh, ww, c = h.shape
-    tok = torch.empty((n, tpad, c), dtype=BF16, device=h.device)
-    check(_lib.load().adm_pool_prep(_ptr(h, BF16, "h"), _ptr(aff[0], torch.float32), _ptr(aff[1], torch.float32),
+    tok = torch.empty((n, tpad, c), dtype=h.dtype, device=h.device)
+    check(_L(h).adm_pool_prep(_ptr(h, h.dtype, "h"), _ptr(aff[0], torch.float32), _ptr(aff[1], torch.float32),
                                     _ptr(pos, torch.float32, "pos"), _ptr(tok), n, hh * ww, c, tpad, _stream()),
           "adm_pool_prep")
     return tok
@@ -412,7 +423,7 @@ def pool_attn_fwd(qkv, t: int, heads: int):
     c = c3 // 3
     a0 = torch.empty((n, c), dtype=torch.float32, device=qkv.device)
     wts = torch.empty((n, heads, tpad), dtype=torch.float32, device=qkv.device)
-    check(_lib.load().adm_pool_attn_fwd(_ptr(qkv, BF16, "qkv"), _ptr(a0), _ptr(wts), n, t, tpad, heads, c // heads,
+    check(_L(qkv).adm_pool_attn_fwd(_ptr(qkv, qkv.dtype, "qkv"), _ptr(a0), _ptr(wts), n, t, tpad, heads, c // heads,
                                         _stream()), "adm_pool_attn_fwd")
     return a0, wts
 
@@ -421,30 +432,30 @@ def pool_attn_bwd(qkv, wts, da0, t: int, heads: int):
     n, tpad, c3 = qkv.shape
     c = c3 // 3
     dqkv = torch.empty_like(qkv)
-    check(_lib.load().adm_pool_attn_bwd(_ptr(qkv, BF16, "qkv"), _ptr(wts, torch.float32), _ptr(da0, torch.float32),
+    check(_L(qkv).adm_pool_attn_bwd(_ptr(qkv, qkv.dtype, "qkv"), _ptr(wts, torch.float32), _ptr(da0, torch.float32),
                                         _ptr(dqkv), n, t, tpad, heads, c // heads, _stream()), "adm_pool_attn_bwd")
     return dqkv
 
 
 def pool_prep_bwd(dtok, hh: int, ww: int):
     n, tpad, c = dtok.shape
-    dact = torch.empty((n, hh, ww, c), dtype=BF16, device=dtok.device)
-    check(_lib.load().adm_pool_prep_bwd(_ptr(dtok, BF16, "dtok"), _ptr(dact), n, hh * ww, c, tpad, _stream()),
+    dact = torch.empty((n, hh, ww, c), dtype=dtok.dtype, device=dtok.device)
+    check(_L(dtok).adm_pool_prep_bwd(_ptr(dtok, dtok.dtype, "dtok"), _ptr(dact), n, hh * ww, c, tpad, _stream()),
           "adm_pool_prep_bwd")
     return dact
 
 
-def pack_conv_weight_bwd(w):
+def pack_conv_weight_bwd(w, dtype=BF16):
     """Backward-data image of a conv weight [cout, cin, ...]: conv with cin' = cout, cout' = cin, flipped taps."""
     cout, cin = w.shape[0], w.shape[1]
     taps = 1
     for s in w.shape[2:]:
         taps *= s
-    lib = _lib.load()
+    lib = _lib.load("f16" if dtype == F16 else "bf16")
     elems = lib.adm_packed_weight_elems(cin, cout, taps)
     if elems < 0:
         raise AdmError(f"pack_conv_weight_bwd: unsupported weight shape {tuple(w.shape)} (cout % 32 == 0, taps 1|9)")
     w32 = w.detach().to(torch.float32).contiguous()
-    out = torch.empty((elems,), dtype=BF16, device=w.device)
+    out = torch.empty((elems,), dtype=dtype, device=w.device)
     check(lib.adm_pack_conv_weight_bwd(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight_bwd")
     return out

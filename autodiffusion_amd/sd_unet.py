@@ -97,7 +97,7 @@ class UNetModel(HipModule):
             raise AdmError("latent UNetModel: parameters are on the CPU; call .to(device) first (no CPU fallback)")
         pr = _Prep()
         f32 = lambda k: P[k].to(torch.float32).contiguous()  # noqa: E731
-        pack = ops.pack_conv_weight
+        pack = lambda w: ops.pack_conv_weight(w, self.compute_dtype)  # noqa: E731
         pr.te0_w, pr.te0_b = f32("time_embed.0.weight"), f32("time_embed.0.bias")
         pr.te2_w, pr.te2_b = f32("time_embed.2.weight"), f32("time_embed.2.bias")
         ws, bs, off = [], [], 0
@@ -211,7 +211,7 @@ class UNetModel(HipModule):
         for blk in seq:
             d = pr.blocks[blk.prefix]
             if isinstance(blk, SDStemSpec):
-                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32), d["w"], d["b"], blk.cout, 9, want_stats=True)
+                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32, self.compute_dtype), d["w"], d["b"], blk.cout, 9, want_stats=True)
             elif isinstance(blk, SDResBlockSpec):
                 h = self._resblock(pr, blk, h, skip if first else None, emb)
             elif isinstance(blk, SDTransformerSpec):
@@ -261,8 +261,8 @@ class UNetModel(HipModule):
             raise AdmError("latent UNetModel.forward: context must be a device tensor (no CPU fallback)")
         with torch.no_grad():
             rows = 128 if s_ctx <= 128 else 256
-            ctx_map = torch.zeros((n, rows, plan.context_dim), dtype=torch.bfloat16, device=context.device)
-            ctx_map[:, :s_ctx] = context.to(torch.bfloat16)
+            ctx_map = torch.zeros((n, rows, plan.context_dim), dtype=self.compute_dtype, device=context.device)
+            ctx_map[:, :s_ctx] = context.to(self.compute_dtype)
             ctx_map = ctx_map.view(n, rows // 16, 16, plan.context_dim)
             kvs = {}
             for b in plan.all_blocks():

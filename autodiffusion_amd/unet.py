@@ -57,8 +57,20 @@ class HipModule:
 
     compute_dtype = torch.bfloat16  # what the kernels compute in, whatever `dtype` (the reference's attribute) says
 
+    def set_torso(self, torso: str):
+        """16-bit element type of activations and weights between kernels: "bf16" (default; BASELINE config 2) or "fp16"
+        (the reference's own torso type under use_fp16=True: 11 mantissa bits instead of 8, the same kernels built for
+        IEEE half, libadm_hip_f16.so).  Accumulation, GroupNorm statistics, softmax, embeddings, sampler stay fp32."""
+        if torso not in ("bf16", "fp16"):
+            raise ValueError(f"torso must be 'bf16' or 'fp16', got {torso!r}")
+        self.compute_dtype = torch.float16 if torso == "fp16" else torch.bfloat16
+        self._packed = None
+        return self
+
     def __init__(self, plan: UNetPlan, use_fp16: bool):
         self.plan = plan
+        if os.environ.get("ADM_TORSO", "bf16") == "fp16" and not getattr(self, "with_backward", False):
+            self.compute_dtype = torch.float16   # the classifier's backward network stays bf16 (gradient range)
         self.dtype = torch.float16 if use_fp16 else torch.float32  # reference attribute (unet.py:464)
         self._params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._packed = None
@@ -198,6 +210,9 @@ class AdmNet(HipModule):
             raise AdmError("UNetModel: parameters are on the CPU; call .to(device) first "
                            "(the HIP path has no CPU fallback)")
         pr = _Prep()
+        cd = self.compute_dtype
+        pack = lambda w: ops.pack_conv_weight(w, cd)          # noqa: E731
+        pack_bwd = lambda w: ops.pack_conv_weight_bwd(w, cd)  # noqa: E731
         f32 = lambda k: P[k].to(torch.float32).contiguous()  # noqa: E731
         pr.te0_w, pr.te0_b = f32("time_embed.0.weight"), f32("time_embed.0.bias")
         pr.te2_w, pr.te2_b = f32("time_embed.2.weight"), f32("time_embed.2.bias")
@@ -213,7 +228,7 @@ class AdmNet(HipModule):
                 w = P[f"{p}.weight"].to(torch.float32)
                 wpad = torch.zeros((b.cout, 32, 3, 3), dtype=torch.float32, device=dev)
                 wpad[:, :b.cin] = w
-                pr.blocks[p] = dict(w=ops.pack_conv_weight(wpad), b=f32(f"{p}.bias"))
+                pr.blocks[p] = dict(w=pack(wpad), b=f32(f"{p}.bias"))
             elif isinstance(b, ResBlockSpec):
                 ws.append(f32(f"{p}.emb_layers.1.weight"))
                 bs.append(f32(f"{p}.emb_layers.1.bias"))
@@ -221,19 +236,19 @@ class AdmNet(HipModule):
                 off += 2 * b.cout
                 d = dict(
                     g1=f32(f"{p}.in_layers.0.weight"), b1=f32(f"{p}.in_layers.0.bias"),
-                    w1=ops.pack_conv_weight(P[f"{p}.in_layers.2.weight"]), c1b=f32(f"{p}.in_layers.2.bias"),
+                    w1=pack(P[f"{p}.in_layers.2.weight"]), c1b=f32(f"{p}.in_layers.2.bias"),
                     g2=f32(f"{p}.out_layers.0.weight"), b2=f32(f"{p}.out_layers.0.bias"),
-                    w2=ops.pack_conv_weight(P[f"{p}.out_layers.3.weight"]), c2b=f32(f"{p}.out_layers.3.bias"),
+                    w2=pack(P[f"{p}.out_layers.3.weight"]), c2b=f32(f"{p}.out_layers.3.bias"),
                 )
                 if b.has_skip_conv:
-                    d["ws"] = ops.pack_conv_weight(P[f"{p}.skip_connection.weight"])
+                    d["ws"] = pack(P[f"{p}.skip_connection.weight"])
                     d["wsb"] = f32(f"{p}.skip_connection.bias")
                 pr.blocks[p] = d
             elif isinstance(b, AttnSpec):
                 pr.blocks[p] = dict(
                     g=f32(f"{p}.norm.weight"), b=f32(f"{p}.norm.bias"),
-                    wqkv=ops.pack_conv_weight(P[f"{p}.qkv.weight"]), bqkv=f32(f"{p}.qkv.bias"),
-                    wproj=ops.pack_conv_weight(P[f"{p}.proj_out.weight"]), bproj=f32(f"{p}.proj_out.bias"),
+                    wqkv=pack(P[f"{p}.qkv.weight"]), bqkv=f32(f"{p}.qkv.bias"),
+                    wproj=pack(P[f"{p}.proj_out.weight"]), bproj=f32(f"{p}.proj_out.bias"),
                 )
         pr.film_w = torch.cat(ws, dim=0).contiguous()
         pr.film_b = torch.cat(bs, dim=0).contiguous()
@@ -244,17 +259,17 @@ class AdmNet(HipModule):
                 p = b.prefix
                 d = pr.blocks[p]
                 if isinstance(b, StemSpec):
-                    d["w_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.weight"])
+                    d["w_bwd"] = pack_bwd(P[f"{p}.weight"])
                     zmax = max(zmax, b.cin, b.cout)
                 elif isinstance(b, ResBlockSpec):
-                    d["w1_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.in_layers.2.weight"])
-                    d["w2_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.out_layers.3.weight"])
+                    d["w1_bwd"] = pack_bwd(P[f"{p}.in_layers.2.weight"])
+                    d["w2_bwd"] = pack_bwd(P[f"{p}.out_layers.3.weight"])
                     if b.has_skip_conv:
-                        d["ws_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.skip_connection.weight"])
+                        d["ws_bwd"] = pack_bwd(P[f"{p}.skip_connection.weight"])
                     zmax = max(zmax, b.cin, b.cout)
                 elif isinstance(b, AttnSpec):
-                    d["wqkv_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.qkv.weight"])
-                    d["wproj_bwd"] = ops.pack_conv_weight_bwd(P[f"{p}.proj_out.weight"])
+                    d["wqkv_bwd"] = pack_bwd(P[f"{p}.qkv.weight"])
+                    d["wproj_bwd"] = pack_bwd(P[f"{p}.proj_out.weight"])
                     zmax = max(zmax, 3 * b.channels)
             pr.zero_bias = torch.zeros(zmax, dtype=torch.float32, device=dev)
         self._prepare_head(pr, P, f32)
@@ -333,7 +348,7 @@ class AdmNet(HipModule):
         for blk in seq:
             if isinstance(blk, StemSpec):
                 d = pr.blocks[blk.prefix]
-                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32), d["w"], d["b"], blk.cout, 9, want_stats=True)
+                h = ops.conv(ops.nchw_to_nhwc_pad(x_nchw, 32, self.compute_dtype), d["w"], d["b"], blk.cout, 9, want_stats=True)
                 if tape is not None:
                     tape.append(("stem", blk, {}))
             elif isinstance(blk, ResBlockSpec):
@@ -368,7 +383,7 @@ class UNetModel(AdmNet):
     def _prepare_head(self, pr, P, f32):
         h = self.plan.head
         pr.head = dict(g=f32(f"{h.prefix}.0.weight"), b=f32(f"{h.prefix}.0.bias"),
-                       w=ops.pack_conv_weight(P[f"{h.prefix}.2.weight"]), cb=f32(f"{h.prefix}.2.bias"))
+                       w=ops.pack_conv_weight(P[f"{h.prefix}.2.weight"], self.compute_dtype), cb=f32(f"{h.prefix}.2.bias"))
 
     def forward(self, x, timesteps, y=None, skip_layer: Sequence[int] = ()):
         """x fp32 [N,C,H,W], timesteps [N] (original-process timesteps), y int64 [N] or None."""

@@ -165,6 +165,7 @@ def run_sd(args, rank, world, dev, red_dev):
     from autodiffusion_amd.sd_unet import UNetModel
     n = args.batch or 6
     unet = UNetModel(image_size=32, use_spatial_transformer=True, **SD_V1).to(dev)
+    unet.set_torso(args.torso)
     unet.randomize_(1234).enable_graph().enable_splitk(os.environ.get("ADM_SD_SPLITK", "1") != "0")
     sampler = DDIMSampler(LatentDiffusion(unet, device=dev))
     g = torch.Generator(device=dev).manual_seed(99)
@@ -221,10 +222,10 @@ def run_sd(args, rank, world, dev, red_dev):
             "metric": "latents/sec (node), Stable-Diffusion v1 latent UNet, 6-step searched DDIM, guidance 7.5",
             "value": round(value, 2), "unit": "latents/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16",
+            "vs_baseline": None, "dtype": "bf16" if args.torso == "bf16" else "f16",
             "data": "synthetic (x_T ~ N(0,1), conditioning ~ N(0,1) [N,77,768], random-init weights of the SD v1 UNet architecture)",
             "config": {"workload": f"Stable-Diffusion v1 latent UNet (859.5 M), searched DDIM {SD_CAND}, classifier-free guidance 7.5, "
-                                   f"{n} latents per GPU and step (64x64x4), bf16, hipGraph replay; VAE / CLIP / FID not on this path",
+                                   f"{n} latents per GPU and step (64x64x4), {args.torso}, hipGraph replay; VAE / CLIP / FID not on this path",
                        "global_batch": world * n, "latent_size": 64, "sampler_steps": len(SD_CAND),
                        "parallelism": f"dp{world} (latent-sharded, no data-path collective)"},
             "model_tflops": round(value * 2 * len(SD_CAND) * SD_GFLOP_LATENT / 1e3, 1),
@@ -241,6 +242,9 @@ def main():
                     help="auto/guided = the headline (ADM-G ImageNet-64, BASELINE configs[1]); adm256 = ADM LSUN-256 dynamic UNet, "
                          "uniform 5-step DDIM (the north star's 256x256 line); sd = BASELINE config 4 "
                          "(Stable-Diffusion v1 latent UNet, 6 searched DDIM steps, classifier-free guidance 7.5)")
+    ap.add_argument("--torso", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit element type of the UNet torso: bf16 (BASELINE configs[1] names it) or fp16 (the reference's own "
+                         "torso type, libadm_hip_f16.so: same kernels, 11 mantissa bits; the classifier's backward network stays bf16)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse N ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -295,6 +299,7 @@ def main():
     model, diffusion = create_model_and_diffusion(**args_to_dict(argparse.Namespace(**flags),
                                                                  model_and_diffusion_defaults().keys()))
     model.to(dev).randomize_(1234).convert_to_fp16()
+    model.set_torso(args.torso)
     classifier = None
     if guided:
         try:
@@ -392,17 +397,17 @@ def main():
         gflop_img = len(schedule) * (gflop_unet + (GFLOP_GUIDE if guided else 0.0))
         if w256:
             wl = (f"ADM LSUN-256 dynamic UNet (552.8 M), unconditional, uniform {len(schedule)}-step DDIM {schedule}, "
-                  f"batch={B} per GPU, bf16")
+                  f"batch={B} per GPU, {args.torso}")
         else:
             wl = (("ADM-G ImageNet-64 classifier-guided" if guided else
                    "ADM ImageNet-64 class-conditional, UNGUIDED (classifier guidance not in this run)")
-                  + f", searched 4-step DDIM {schedule}, batch={B} per GPU, bf16")
+                  + f", searched 4-step DDIM {schedule}, batch={B} per GPU, {args.torso}")
         out = {
             "metric": ("images/sec (node), ADM LSUN-256 5-step DDIM" if w256 else
                        "images/sec (node), ADM-G ImageNet-64 4-step DDIM"),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.torso == "bf16" else "f16",
             "data": ("synthetic (x_T ~ N(0,1), random-init weights of the ADM LSUN-256 architecture)" if w256 else
                      "synthetic (x_T ~ N(0,1), y ~ U{0..999}, random-init weights of the ADM-G-64 architecture)"),
             "config": {"workload": wl,
