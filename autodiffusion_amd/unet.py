@@ -45,9 +45,10 @@ def warn_compute_dtype(what: str, flag: str):
     _warned_precision.add(flag)
     import warnings
     from . import logger
-    msg = (f"{what}: {flag}=False asks for the reference's fp32 network; the MI355X HIP path computes in bf16 with fp32 "
-           "accumulation, GroupNorm statistics, softmax and embeddings (one evaluation differs from the reference's fp32 "
-           "result by ~1e-2 relative, tests/test_hip_fullsize.py; its own fp16 torso differs by 1.4e-3)")
+    msg = (f"{what}: {flag}=False asks for the reference's fp32 network; the MI355X HIP path computes with a 16-bit torso "
+           "(bf16 by default, fp16 with model.set_torso('fp16') / ADM_TORSO=fp16) and fp32 accumulation, GroupNorm "
+           "statistics, softmax and embeddings: one evaluation differs from the reference's fp32 result by ~1e-2 relative in "
+           "bf16, 1.3e-3 in fp16 (the reference's own fp16 torso: 1.4e-3; tests/test_hip_fullsize.py)")
     logger.warn("WARNING: " + msg)
     warnings.warn(msg, stacklevel=3)
 

@@ -18,8 +18,12 @@ def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(_lib.SIGNATURES)
 
 
-def test_library_loads_and_exports_every_symbol():
-    lib = _lib.load()
+import pytest
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])   # libadm_hip.so and its IEEE-half build libadm_hip_f16.so
+def test_library_loads_and_exports_every_symbol(kind):
+    lib = _lib.load(kind)
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     assert lib.adm_abi_version() == _lib.ABI_VERSION

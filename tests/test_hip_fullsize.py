@@ -165,8 +165,10 @@ def test_adm128_unet_classifier_and_guided_10_step_loop_match_the_reference():
     x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))
     out = model(x, t, y)
     r = rel(out, g["out"])
-    print(f"full ADM-128 UNet rel {r:.3e}")
-    assert torch.isfinite(out).all() and r < 2e-2, r
+    r16 = rel(model.set_torso("fp16")(x, t, y), g["out"])
+    model.set_torso("bf16")
+    print(f"full ADM-128 UNet rel {r:.3e} (fp16 torso: {r16:.3e})")
+    assert torch.isfinite(out).all() and r < 2e-2 and r16 < 4e-3, (r, r16)
     c128 = clf(128, 2)
     grad, logits = c128.log_prob_grad(x, t, y, 1.0, return_logits=True)
     rl = float((logits.cpu() - torch.from_numpy(g["logits"])).abs().max() / np.abs(g["logits"]).max())
@@ -199,6 +201,9 @@ def test_lsun256_dynamic_unet_matches_the_reference():
         rn = abs(float(out.double().norm()) / float(g[f"{tag}_norm"]) - 1.0)
         print(f"full LSUN-256 UNet ({tag}): rel {r:.3e}, norm ratio off by {rn:.3e}")
         assert torch.isfinite(out).all() and r < 2e-2 and rn < 1e-2, (tag, r, rn)
+    r16 = rel(model.set_torso("fp16")(x, t, None)[:, :, ::2, ::2], g["out_sub"])
+    print(f"full LSUN-256 UNet, fp16 torso: rel {r16:.3e}")
+    assert r16 < 4e-3, r16
 
 
 def test_sd_v1_latent_unet_matches_the_reference():
@@ -222,3 +227,6 @@ def test_sd_v1_latent_unet_matches_the_reference():
     rk = rel(outk, g["out"])
     print(f"full SD v1 latent UNet, split-K schedule: rel {rk:.3e}; vs the one-pass schedule {rel(outk, out.cpu().numpy()):.3e}")
     assert torch.isfinite(outk).all() and rk < 2e-2 and not torch.equal(outk, out), rk
+    r16 = rel(m.set_torso("fp16")(*args), g["out"])
+    print(f"full SD v1 latent UNet, fp16 torso (split-K schedule): rel {r16:.3e}")
+    assert r16 < 5e-3, r16

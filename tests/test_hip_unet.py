@@ -98,3 +98,26 @@ def test_unet_requires_y_iff_class_cond_and_device_tensors():
         m(x.cpu(), t, torch.zeros(1, dtype=torch.int64, device=DEV))
     with pytest.raises(TypeError):
         m(x, t, torch.zeros(1, dtype=torch.int64, device=DEV), skip_layer=[1])
+
+
+def test_fp16_torso_small_goldens_at_the_reference_precision():
+    """`set_torso("fp16")` (libadm_hip_f16.so): the golden models of this file -- dynamic skip lists, legacy attention
+    order, 64x64 -- against the reference's fp32 outputs at the tolerance of the reference's own fp16 torso: relative
+    Frobenius error <= 4e-3 (5 x tighter than the bf16 bound), batch independence intact."""
+    g = golden("unet_m32")
+    m = _model(plan_m32(dynamic=True)).set_torso("fp16")
+    x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))
+    for tag in ("none", "a", "b", "all"):
+        check(m(x, t, y, skip_layer=g[f"skip_{tag}"].tolist()), g[f"out_{tag}"], f"fp16 m32 skip_{tag}", 4e-3, 2e-2)
+    g = golden("unet_m32_legacy")
+    m = _model(plan_m32(dynamic=False, legacy=True)).set_torso("fp16")
+    check(m(*(torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))), g["out"], "fp16 m32 legacy", 4e-3, 2e-2)
+    g = golden("unet_m64")
+    m = _model(plan_m64()).set_torso("fp16")
+    x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))
+    out = m(x, t, y)
+    check(out, g["out"], "fp16 m64", 4e-3, 2e-2)
+    x5 = torch.cat([x, x, x[:1]])
+    out5 = m(x5, torch.cat([t, t, t[:1]]), torch.cat([y, y, y[:1]]))
+    assert torch.equal(out5[:2], out) and torch.equal(out5[4], out[0])
+    assert torch.equal(m.set_torso("bf16")(x, t, y), _model(plan_m64())(x, t, y))   # and back: the bf16 result
