@@ -188,3 +188,28 @@ def test_sampling_cli_writes_the_reference_npz_format(tmp_path):
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def test_image_sample_cli_unconditional_npz(tmp_path):
+    """scripts/image_sample.py (reference scripts/image_sample.py:81-159): unguided sampling, arr_0 only when the model is
+    not class-conditional, the searched-subset flag, the reference's log lines."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("image_sample", os.path.join(root, "scripts", "image_sample.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    flags = ("--image_size 32 --num_channels 32 --num_res_blocks 1 --channel_mult 1,2,2 --attention_resolutions 16,8 "
+             "--num_head_channels 32 --class_cond False --learn_sigma True --resblock_updown True --noise_schedule cosine "
+             "--use_scale_shift_norm True --use_fp16 True --use_ddim True --batch_size 4 --num_samples 6").split()
+    out = mod.main(flags + ["--save_dir", str(tmp_path), "--use_timestep", "[0, 250, 500, 750]"])
+    assert os.path.basename(out) == "samples_6x32x32x3.npz"
+    z = np.load(out)
+    assert z.files == ["arr_0"] and z["arr_0"].shape == (6, 32, 32, 3) and z["arr_0"].dtype == np.uint8
+    log = open(os.path.join(str(tmp_path), "log.txt")).read()
+    assert "sampling..." in log and "created 8 samples" in log and "sampling time: " in log and "sampling complete" in log
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
