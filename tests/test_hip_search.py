@@ -213,3 +213,38 @@ def test_image_sample_cli_unconditional_npz(tmp_path):
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def test_get_cand_fid_with_a_reference_style_evaluator_object(monkeypatch):
+    """The host path of get_cand_fid: an object with the reference Evaluator_v1's `compute_activations(batches, batch_size)
+    -> (pool, spatial)` (evaluator_v1.py:252-280), fed the uint8 NHWC numpy array `arr[:num_samples]` exactly as
+    search_imagenet64_classifier_guidance.py:362-366 does, against the device-statistics path with the same features."""
+    from autodiffusion_amd import logger, search
+    from autodiffusion_amd.fid import FIDStatistics
+    model, clf, diffusion = _setup()
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    proj = torch.randn(3 * 64 * 64, 32, generator=torch.Generator().manual_seed(5)) / 100.0
+    seen = []
+
+    class HostEvaluator:   # TEST stand-in for the TensorFlow Inception session (unavailable offline)
+        def compute_activations(self, batches, batch_size):
+            assert isinstance(batches, np.ndarray) and batches.dtype == np.uint8 and batches.shape[1:] == (64, 64, 3)
+            seen.append((batches.shape[0], batch_size))
+            preds = [batches[i:i + batch_size].reshape(-1, 3 * 64 * 64).astype(np.float32) @ proj.numpy()
+                     for i in range(0, batches.shape[0], batch_size)]
+            pool = np.concatenate(preds, axis=0)
+            return pool, pool[:, :7]
+
+    args = SimpleNamespace(max_epochs=1, select_num=2, population_num=3, m_prob=0.25, crossover_num=1, mutation_num=1,
+                           batch_size=4, num_samples=10, image_size=64, use_ddim=True, clip_denoised=True,
+                           class_cond=True, classifier_scale=1.0, seed=0, time_step=4, use_ddim_init_x=True)
+    ref = FIDStatistics(np.zeros(32), np.eye(32))
+    cand = [153, 424, 926, 690]
+    s_host = search.EvolutionSearcher(args, model, diffusion, 4, classifier=clf, evaluator=HostEvaluator(), ref_stats=ref)
+    fid_host = s_host.get_cand_fid(cand=cand, args=args)
+    assert seen == [(10, 64)]                       # arr[:num_samples], the reference's batch size of 64
+    dev_proj = proj.to(DEV)
+    s_dev = search.EvolutionSearcher(args, model, diffusion, 4, classifier=clf, feature_dim=32, ref_stats=ref,
+                                     features=lambda u8: u8.reshape(u8.shape[0], -1).float() @ dev_proj)
+    fid_dev = s_dev.get_cand_fid(cand=cand, args=args)
+    assert np.isfinite(fid_host) and abs(fid_host - fid_dev) <= 1e-5 * max(1.0, abs(fid_dev)), (fid_host, fid_dev)
