@@ -53,216 +53,6 @@ struct AttnK {
   float scale_log2;  // log2(e) / sqrt(D)
 };
 
-// (256, 2): two waves per SIMD caps the kernel at 256 registers, which also makes hipcc keep the MFMA
-// accumulators in VGPRs -- with the default bound it parked them in AGPRs and spent ~160 v_accvgpr_read/write
-// per key tile moving S^T out for the softmax and O^T through the rescale.
-template <int D>
-__global__ void __launch_bounds__(256, D <= 64 ? 2 : 0)
-attn_kernel_v1(const AttnK p) {
-  constexpr int KS = D / 32;   // 32-deep k-steps of QK^T
-  constexpr bool R16 = (D % 32) == 16;  // plus one 16-deep step (v_mfma_f32_16x16x16_bf16): head widths 48, 80, 112
-  static_assert(D % 16 == 0 && KS >= 1, "head width must be a multiple of 16, at least 32");
-  constexpr int DT = D / 16;   // d tiles of the output
-  // LDS row pitch = 8 mod 16 dwords (conflict-free for the b128 fragment reads and the transposing reads): 48- and
-  // 80-wide heads have it unpadded (24 / 40 dwords), the multiples of 32 need the 16-element pad
-  constexpr int KROW = D + (((D / 2) % 16 == 8) ? 0 : PADE);
-  // K and V tiles row-major, double-buffered: the next tile's global loads fly during this tile's MFMAs
-  __shared__ __attribute__((aligned(16))) uint16_t Ks[2][KT * KROW];
-  __shared__ __attribute__((aligned(16))) uint16_t Vs[2][KT * KROW];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lc = lane & 15, lq = lane >> 4;
-  int bx, by;
-  adm_xcd_block(bx, by);
-  const int n = by / p.heads, hd = by % p.heads;
-  const int qbase = bx * QB + wave * QW;
-  const uint16_t* base = p.qkv + (long long)n * p.T * p.C3;
-  const int qcol = p.q_off + hd * p.head_stride, kcol = p.k_off + hd * p.kv_head_stride,
-            vcol = p.v_off + hd * p.kv_head_stride;
-  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kv + (long long)n * p.kv_rows * p.Ckv), 0,
-                                                                       p.Tk * p.Ckv * 2, 0x00020000);
-
-  // one descriptor over this image's T rows: queries / keys beyond T read as zeros (no bounds branches)
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.T * p.C3 * 2, 0x00020000);
-  // Q^T fragments: lane (query lc, quarter lq) holds Q[query][ks*32 + 8*lq .. +8]
-  adm_h8 qf[2][KS];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int q = qbase + qt * 16 + lc;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const adm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * p.C3 + qcol + ks * 32 + lq * 8) * 2, 0, 0);
-      qf[qt][ks] = __builtin_bit_cast(adm_h8, v);
-    }
-  }
-  adm_s16x4 qf16[2] = {};  // the 16-deep tail: lane (query lc, quarter lq) holds Q[query][32*KS + 4*lq .. +4]
-  if constexpr (R16) {
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int q = qbase + qt * 16 + lc;
-      const adm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (q * p.C3 + qcol + KS * 32 + lq * 4) * 2, 0, 0);
-      qf16[qt] = __builtin_bit_cast(adm_s16x4, v);
-    }
-  }
-
-  f32x4 oacc[DT][2];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
-
-  AdmTileRegs<KT, D, 256> kr, vr;
-  kr.load_buf(rsk, p.Ckv, kcol, 0, tid);
-  vr.load_buf(rsk, p.Ckv, vcol, 0, tid);
-  kr.store(Ks[0], KROW, tid);
-  vr.store(Vs[0], KROW, tid);
-  __syncthreads();
-
-  const int ntiles = (p.Tk + KT - 1) / KT;
-  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
-    const int k0 = kt0 * KT;
-    const int cur = kt0 & 1;
-    const bool next = kt0 + 1 < ntiles;
-    if (next) {
-      kr.load_buf(rsk, p.Ckv, kcol, k0 + KT, tid);
-      vr.load_buf(rsk, p.Ckv, vcol, k0 + KT, tid);
-    }
-    const uint16_t* Kc = Ks[cur];
-    const uint16_t* Vc = Vs[cur];
-
-    // ---- S^T = K . Q^T  (4 key tiles x 2 query tiles).  All K fragments of the tile are requested first
-    //      (scheduling fences keep hipcc from sinking each LDS read next to its two MFMAs, which exposed the
-    //      read latency 8 times per tile); the V^T fragments are requested right after the S MFMAs so that
-    //      their latency hides under the softmax VALU work.
-    __builtin_amdgcn_sched_barrier(0);
-    adm_h8 kfr[4][KS];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        kfr[kt][ks] = *reinterpret_cast<const adm_h8*>(&Kc[(kt * 16 + lc) * KROW + ks * 32 + lq * 8]);
-    adm_s16x4 kfr16[4] = {};
-    if constexpr (R16) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        kfr16[kt] = *reinterpret_cast<const adm_s16x4*>(&Kc[(kt * 16 + lc) * KROW + KS * 32 + lq * 4]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 st[4][2];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-        st[kt][qt] = adm_mfma_16x16x32(kfr[kt][0], qf[qt][0], zero4, 0, 0, 0);
-#pragma unroll
-      for (int ks = 1; ks < KS; ++ks)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = adm_mfma_16x16x32(kfr[kt][ks], qf[qt][ks], st[kt][qt], 0, 0, 0);
-      if constexpr (R16) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          st[kt][qt] = adm_mfma_16x16x16(kfr16[kt], qf16[qt], st[kt][qt], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    adm_h8 vfr[DT][2];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) vfr[dt][kb] = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- online softmax (per query column)
-    const bool ragged = k0 + KT > p.Tk;
-    adm_h8 pf[2][2];  // [query tile][32-key block]
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float mx = -1e30f;
-      if (ragged) {  // only the last tile of a sequence whose length is not a multiple of 64
-        asm volatile("" ::: "memory");  // keep this a (wave-uniform) branch: if-converted it is 32 compares + selects per tile
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (k0 + kt * 16 + lq * 4 + r >= p.Tk) st[kt][qt][r] = -1e30f;
-      }
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][qt][r]);
-      mx = adm_quarter_max(mx);
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * p.scale_log2);
-      const float mneg = -m_new * p.scale_log2;
-      m_run[qt] = m_new;
-      // exponent arguments and the row sum in packed fp32 (v_pk_fma_f32 / v_pk_add_f32): this loop is VALU-bound
-      const adm_f32x2 sc2 = {p.scale_log2, p.scale_log2}, mn2 = {mneg, mneg};
-      adm_f32x2 ps2 = {0.f, 0.f};
-      float pv[4][4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const adm_f32x2 a = __builtin_elementwise_fma(adm_f32x2{st[kt][qt][2 * h], st[kt][qt][2 * h + 1]}, sc2, mn2);
-          const adm_f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-          pv[kt][2 * h] = e.x;
-          pv[kt][2 * h + 1] = e.y;
-          ps2 += e;
-        }
-      const float psum = ps2.x + ps2.y;
-      l_run[qt] = l_run[qt] * alpha + psum;
-      if (__any(alpha != 1.0f)) {  // wave-uniform: skip the O rescale once the running max has settled
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
-      }
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        adm_h8 f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (adm_elem_t)pv[2 * kb + (e >> 2)][e & 3];
-        pf[qt][kb] = f;
-      }
-    }
-    // ---- O^T += V^T . P^T ; contraction slot k = 8*lq + e  <->  key kb*32 + 16*(e>>2) + 4*lq + (e&3);
-    //      V^T fragments came from the row-major tile through the transposing LDS read
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          oacc[dt][qt] = adm_mfma_16x16x32(vfr[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
-    if (next) {
-      kr.store(Ks[cur ^ 1], KROW, tid);
-      vr.store(Vs[cur ^ 1], KROW, tid);
-    }
-    __syncthreads();
-  }
-
-  // ---- normalise and store: lane holds d = dt*16 + 4*lq .. +3 of query lc
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const float l = adm_quarter_sum(l_run[qt]);
-    const float inv = 1.0f / l;
-    const int q = qbase + qt * 16 + lc;
-    if (q >= p.T) continue;
-    // log2-domain log-sum-exp of the scaled logits: P = exp2(s * scale_log2 - lse)
-    if (p.lse && lq == 0) p.lse[((long long)n * p.heads + hd) * p.T + q] = m_run[qt] * p.scale_log2 + log2f(l);
-    uint16_t* orow = p.out + ((long long)n * p.T + q) * p.C + hd * D;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      const f32x4 o = oacc[dt][qt] * inv;
-      uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
-      *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
-    }
-  }
-}
-
 // Second build of the tuned kernel (round 2).  Per 64-key tile a wave issues 32 MFMAs (512 cycles of matrix pipe); the
 // first build also issued ~130 VALU instructions + 32 v_exp_f32 around them, at 164 registers = 3 waves per SIMD.
 // Ablations on MI355X (tools/attn_ablate.py: drop one piece, time the rest) price every piece of the loop at 15-25 % of
@@ -488,15 +278,7 @@ attn_kernel(const AttnK p) {
         vfr[slot][kb] = DMA ? adm_tr_frag_swz(Vc, kb * 32, dt * 16, lc, lq) : adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
 #endif
     };
-#ifdef ADM_ATTN_NOROLLV
-    adm_h8 vall[DT][2];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) vall[dt][kb] = adm_tr_frag(Vc, KROW, kb * 32, dt * 16, lc, lq);
-#else
     vread(0, 0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     ATT_T(2);
     if constexpr (RAG) {  // keys beyond Tk (their K rows read as zeros): weight 0
@@ -571,19 +353,13 @@ attn_kernel(const AttnK p) {
       for (int qt = 0; qt < 2; ++qt) lacc[qt] = adm_mfma_16x16x32(ones, pf[qt][kb], lacc[qt], 0, 0, 0);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-#ifndef ADM_ATTN_NOROLLV
       if (dt + 1 < DT) vread(dt + 1, (dt + 1) & 1);
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
-#ifdef ADM_ATTN_NOROLLV
-          oacc[dt][qt] = adm_mfma_16x16x32(vall[dt][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
-#else
           oacc[dt][qt] = adm_mfma_16x16x32(vfr[dt & 1][kb], pf[qt][kb], oacc[dt][qt], 0, 0, 0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     ATT_T(5);
@@ -810,8 +586,6 @@ int launch_attention(const AttnK& k, int n, int t, int heads, int d, hipStream_t
     else hipLaunchKernelGGL((attn_wide_kernel<256>), gridw, dim3(256), 0, s, k);
     return adm_check_launch("adm_attention");
   }
-  static const bool v1 = getenv("ADM_ATTN_V1") != nullptr;  // A/B switch against the round-1 kernel (measurements only)
-  if (v1 && d == 64) { hipLaunchKernelGGL((attn_kernel_v1<64>), grid, dim3(256), 0, s, k); return adm_check_launch("adm_attention"); }
   if (d == 32) hipLaunchKernelGGL((attn_kernel<32>), grid, dim3(256), 0, s, k);
   else if (d == 48) hipLaunchKernelGGL((attn_kernel<48>), grid, dim3(256), 0, s, k);
   else if (d == 80) hipLaunchKernelGGL((attn_kernel<80>), grid, dim3(256), 0, s, k);
