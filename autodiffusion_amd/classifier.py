@@ -148,11 +148,19 @@ class EncoderUNetModel(AdmNet):
         """scale * grad_x sum_n log_softmax(f(x,t))[n, y_n]; fp32 [N,3,H,W]."""
         if not x.is_cuda:
             raise AdmError("EncoderUNetModel.log_prob_grad: x must be a device tensor (no CPU fallback)")
+        if self.use_graph and ops.CONV_PROFILE is None and timesteps.is_cuda:
+            self._packed or self._prepare()
+            ins = (x.detach().to(torch.float32).contiguous(), timesteps.contiguous(), y.to(torch.int64).contiguous())
+            g, logits = self._graphed(("grad", float(scale)), lambda x_, t_, y_: self._log_prob_grad(x_, t_, y_, scale), ins)
+            return (g, logits) if return_logits else g
+        g, logits = self._log_prob_grad(x, timesteps, y, scale)
+        return (g, logits) if return_logits else g
+
+    def _log_prob_grad(self, x, timesteps, y, scale):
         logits, tape = self._forward_tape(x, timesteps)
         with torch.no_grad():
             dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale)
-        g = self._backward_tape(tape, dl)
-        return (g, logits) if return_logits else g
+        return self._backward_tape(tape, dl), logits
 
 
 class _ClassifierFn(torch.autograd.Function):

@@ -23,7 +23,7 @@ NUM_CLASSES = 1000
 class CandidateEvaluator:
     def __init__(self, model, base_diffusion, classifier=None, *, image_size: int, use_ddim: bool = True,
                  clip_denoised: bool = True, class_cond: bool = True, classifier_scale: float = 1.0,
-                 device=None):
+                 device=None, use_graph: bool = False):
         self.model = model
         self.classifier = classifier
         self.base_diffusion = base_diffusion
@@ -35,6 +35,10 @@ class CandidateEvaluator:
         self.classifier_scale = classifier_scale
         self.device = device if device is not None else model.device
         self.skip_layers = None
+        if use_graph:  # hipGraph replay of the UNet evaluation and of the guidance gradient (batches <= ~100: the host's
+            model.enable_graph(True)   # ~60 ms of launch work per guided step is otherwise the floor)
+            if classifier is not None and hasattr(classifier, "enable_graph"):
+                classifier.enable_graph(True)
 
     def set_candidate(self, cand: Union[Sequence[int], dict]):
         """reset_diffusion(cand); dict candidates also carry one skip-layer list per step."""

@@ -84,7 +84,8 @@ class EvolutionSearcher(object):
             self._ev = CandidateEvaluator(
                 model, base_diffusion, classifier, image_size=args.image_size, use_ddim=args.use_ddim,
                 clip_denoised=args.clip_denoised, class_cond=args.class_cond,
-                classifier_scale=getattr(args, "classifier_scale", 1.0), device=dist_util.dev())
+                classifier_scale=getattr(args, "classifier_scale", 1.0), device=dist_util.dev(),
+                use_graph=bool(getattr(args, "use_graph", False)))
             self.active_diffusion = self._ev.active_diffusion
 
     # ------------------------------------------------------------------ evaluate-candidate interface

@@ -246,6 +246,10 @@ def main():
     ap.add_argument("--torso", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type of the UNet torso: bf16 (BASELINE configs[1] names it) or fp16 (the reference's own "
                          "torso type, libadm_hip_f16.so: same kernels, 11 mantissa bits; the classifier's backward network stays bf16)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the UNet evaluation and the guidance gradient as captured hipGraphs (small batches: the host's "
+                         "~60 ms of launch work per guided step is the floor below batch ~100); the roofline's per-launch events "
+                         "then come from one extra eager batch after the timed region")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse N ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -316,7 +320,7 @@ def main():
             classifier, guided = None, False
 
     ev = CandidateEvaluator(model, diffusion, classifier=classifier, image_size=size, use_ddim=True,
-                            classifier_scale=1.0, class_cond=not w256, device=dev)
+                            classifier_scale=1.0, class_cond=not w256, device=dev, use_graph=args.graph)
     ev.set_candidate(schedule)
     B = args.batch
 
@@ -329,7 +333,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not args.graph:
         ops.CONV_PROFILE = []
         # HIP events only around the dominant kernel's launches (all conv launches with --conv-breakdown): a pair of
         # events per launch costs the unguided workload 3.5 % when every conv carries one
@@ -349,6 +353,15 @@ def main():
         elapsed = float(tt.item())
 
     roof = None
+    if args.graph and not args.no_kernel_events:   # the replayed launches carry no events: one eager batch for the roofline
+        model.enable_graph(False)
+        if classifier is not None:
+            classifier.enable_graph(False)
+        ops.CONV_PROFILE, ops.CONV_PROFILE_KEY = [], (None if args.conv_breakdown else dom_key)
+        t0e = time.perf_counter()
+        one_step(args.steps + 1)
+        torch.cuda.synchronize()
+        eager_s = time.perf_counter() - t0e
     if ops.CONV_PROFILE is not None:
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
         # dominant kernel symbol: conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> = fused GN+SiLU prologue, 3x3 conv,
@@ -372,7 +385,9 @@ def main():
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": len(dom), "avg_launch_us": round(ms * 1e3 / len(dom), 2),
                     "avg_launch_gflop": round(fl / len(dom) / 1e9, 3),
-                    "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+                    "share_of_step_time": round(ms * 1e-3 / (eager_s if args.graph else elapsed), 3)}
+            if args.graph:
+                roof["how"] = "one eager batch after the timed region (the timed steps replay hipGraphs, which carry no events)"
             if guided and ev.active_diffusion.overlap_guidance:
                 # in the timed region the guidance gradient runs on a second stream, so the launches above share the CUs
                 # with its kernels (their event-bracketed time is not the kernel's own speed): one extra, untimed batch
@@ -413,7 +428,8 @@ def main():
                      "synthetic (x_T ~ N(0,1), y ~ U{0..999}, random-init weights of the ADM-G-64 architecture)"),
             "config": {"workload": wl,
                        "global_batch": world * B, "image_size": size, "sampler_steps": len(schedule),
-                       "parallelism": f"dp{world} (image-sharded, no data-path collective)"},
+                       "parallelism": f"dp{world} (image-sharded, no data-path collective)",
+                       "launch": "hipGraph replay" if args.graph else "eager"},
             "model_tflops": round(value * gflop_img / 1e3, 1),
             "roofline": roof,
         }

@@ -9,7 +9,8 @@ Result lines ("epoch = i : top k result", "No.j [..] fid = ..") go to ``<save_di
 What this build needs from the user that the reference downloaded: the Inception pool3 feature extractor.
 ``--features pkg.module:factory`` names a callable ``factory(device) -> (features, dim)`` where
 ``features(uint8 NHWC device batch) -> fp32 [B, dim]``; ``--ref_path`` is an .npz with ``mu``, ``sigma``
-(written from the reference's pickled FIDStatistics).  ``--population_parallel True`` shards whole
+(written from the reference's pickled FIDStatistics).  ``--use_graph True`` replays each UNet evaluation / guidance gradient as a captured hipGraph (batches <= ~100 are
+bound by the host launch rate otherwise).  ``--population_parallel True`` shards whole
 candidates over ranks; otherwise every candidate's images are sharded and the statistics pooled.
 
 ``--use_dynamic_unet True`` runs the joint timestep + layer-skip search of
@@ -42,7 +43,7 @@ def create_argparser():
         time_step=100, seed=0, deterministic=False, local_rank=0, max_epochs=20, select_num=10, population_num=50,
         m_prob=0.1, crossover_num=25, mutation_num=35, classifier_path="", classifier_scale=1.0, max_fid=48.0,
         thres=0.2, use_ddim_init_x=False, search_space="", ref_path="", MASTER_PORT="12344", init_x="",
-        without_classifier=False, features="", population_parallel=False, fid_on_device=False,
+        without_classifier=False, features="", population_parallel=False, fid_on_device=False, use_graph=False,
         index_step=None, max_prun=0.0, min_prun=0.0,
     )
     defaults.update(model_and_diffusion_defaults())

@@ -150,3 +150,31 @@ def test_two_stream_guidance_overlap_is_bit_identical():
             ev.active_diffusion.overlap_guidance = overlap
             outs.append(ev.sample_batch(5, seed=11).clone())
         assert torch.equal(outs[-1], outs[-2]) and torch.equal(outs[-2], outs[-3])
+
+
+def test_hipgraph_replay_of_unet_and_guidance_gradient_is_bit_identical():
+    """CandidateEvaluator(use_graph=True): the UNet evaluation and the guidance gradient are captured once per (shapes,
+    layer-skip set, launching stream) and replayed -- guided and unguided, ddim and ddpm, plain and layer-skip candidates,
+    with the gradient on the side stream -- against the eager path, twice (second pass: pure replay)."""
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    model, diffusion, clf = _setup_m64()
+    cases = [([153, 424, 926, 690], None), ([94, 217, 574], [[1], [], [0, 5]])]
+    for use_ddim in (True, False):
+        for classifier in (clf, None):
+            want = []
+            for graph in (False, True, True):
+                model.enable_graph(False)
+                clf.enable_graph(False)
+                ev = CandidateEvaluator(model, diffusion, classifier, image_size=64, use_ddim=use_ddim, device=DEV, use_graph=graph)
+                got = []
+                for steps, skips in cases:
+                    ev.set_candidate(steps if skips is None else {"timesteps": steps, "skip_layers": skips})
+                    got.append(ev.sample_batch(3, seed=5).clone())
+                    got.append(ev.sample_batch(3, seed=6).clone())
+                if not want:
+                    want = got
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b), (use_ddim, classifier is not None, graph)
+    assert len(model._packed.graphs) >= 3 and len(clf._packed.graphs) >= 1     # {no skips, [1], [0, 5]} x streams
+    model.enable_graph(False)
+    clf.enable_graph(False)

@@ -120,4 +120,4 @@ def test_fp16_torso_small_goldens_at_the_reference_precision():
     x5 = torch.cat([x, x, x[:1]])
     out5 = m(x5, torch.cat([t, t, t[:1]]), torch.cat([y, y, y[:1]]))
     assert torch.equal(out5[:2], out) and torch.equal(out5[4], out[0])
-    assert torch.equal(m.set_torso("bf16")(x, t, y), _model(plan_m64())(x, t, y))   # and back: the bf16 result
+    assert torch.equal(m.set_torso("bf16")(x, t, y), _model(plan_m64()).set_torso("bf16")(x, t, y))   # and back: the bf16 result
