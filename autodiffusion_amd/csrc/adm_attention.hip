@@ -401,8 +401,8 @@ attn_kernel(const AttnK p) {
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 o = oacc[dt][qt] * inv;
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
+      pk.x = adm_pack2(o[0], o[1]);
+      pk.y = adm_pack2(o[2], o[3]);
       *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
     }
   }
@@ -507,8 +507,8 @@ attn_wide_kernel(const AttnK p) {
   for (int dt = 0; dt < DT; ++dt) {
     const f32x4 o = oacc[dt] * inv;
     uint2 pk;
-    pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
-    pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
+    pk.x = adm_pack2(o[0], o[1]);
+    pk.y = adm_pack2(o[2], o[3]);
     *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
   }
 }

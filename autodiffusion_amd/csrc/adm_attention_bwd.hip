@@ -166,8 +166,8 @@ attn_dq_kernel(const AttnBwdK p) {
     for (int dt = 0; dt < DT; ++dt) {
       const f32x4 o = acc[dt][qt] * p.inv_sqrt_d;
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_h(o[0]) | ((uint32_t)adm_f32_to_h(o[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_h(o[2]) | ((uint32_t)adm_f32_to_h(o[3]) << 16);
+      pk.x = adm_pack2(o[0], o[1]);
+      pk.y = adm_pack2(o[2], o[3]);
       *reinterpret_cast<uint2*>(orow + dt * 16 + lq * 4) = pk;
     }
   }
@@ -302,11 +302,11 @@ attn_dkv_kernel(const AttnBwdK p) {
       const f32x4 a = dk[dt][kt] * p.inv_sqrt_d;
       const f32x4 b = dv[dt][kt];
       uint2 pk;
-      pk.x = (uint32_t)adm_f32_to_h(a[0]) | ((uint32_t)adm_f32_to_h(a[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_h(a[2]) | ((uint32_t)adm_f32_to_h(a[3]) << 16);
+      pk.x = adm_pack2(a[0], a[1]);
+      pk.y = adm_pack2(a[2], a[3]);
       *reinterpret_cast<uint2*>(orow + kcol + dt * 16 + lq * 4) = pk;
-      pk.x = (uint32_t)adm_f32_to_h(b[0]) | ((uint32_t)adm_f32_to_h(b[1]) << 16);
-      pk.y = (uint32_t)adm_f32_to_h(b[2]) | ((uint32_t)adm_f32_to_h(b[3]) << 16);
+      pk.x = adm_pack2(b[0], b[1]);
+      pk.y = adm_pack2(b[2], b[3]);
       *reinterpret_cast<uint2*>(orow + vcol + dt * 16 + lq * 4) = pk;
     }
   }

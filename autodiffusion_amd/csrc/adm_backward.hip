@@ -162,10 +162,10 @@ gn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__
       r[j] = a8[j] * gg + k18[j] * xx + k08[j] + ad;
     }
     uint4 pk;
-    pk.x = adm_f32_to_h(r[0]) | ((uint32_t)adm_f32_to_h(r[1]) << 16);
-    pk.y = adm_f32_to_h(r[2]) | ((uint32_t)adm_f32_to_h(r[3]) << 16);
-    pk.z = adm_f32_to_h(r[4]) | ((uint32_t)adm_f32_to_h(r[5]) << 16);
-    pk.w = adm_f32_to_h(r[6]) | ((uint32_t)adm_f32_to_h(r[7]) << 16);
+    pk.x = adm_pack2(r[0], r[1]);
+    pk.y = adm_pack2(r[2], r[3]);
+    pk.z = adm_pack2(r[4], r[5]);
+    pk.w = adm_pack2(r[6], r[7]);
     *reinterpret_cast<uint4*>(out + pix * c + ch) = pk;
   }
 }
@@ -190,7 +190,7 @@ add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint1
     for (int j = 0; j < 4; ++j) {
       const float lo = adm_lo_f32(au[j]) + bs * adm_lo_f32(bu[j]);
       const float hi = adm_hi_f32(au[j]) + bs * adm_hi_f32(bu[j]);
-      o[j] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
+      o[j] = adm_pack2(lo, hi);
     }
     *reinterpret_cast<uint4*>(out + pix * c + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -328,8 +328,8 @@ pool_attn_bwd_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int j = j8 * 8 + 2 * e;
-        kk[e] = (uint32_t)adm_f32_to_h(dl * q0[j]) | ((uint32_t)adm_f32_to_h(dl * q0[j + 1]) << 16);
-        vv[e] = (uint32_t)adm_f32_to_h(ws * da[j]) | ((uint32_t)adm_f32_to_h(ws * da[j + 1]) << 16);
+        kk[e] = adm_pack2(dl * q0[j], dl * q0[j + 1]);
+        vv[e] = adm_pack2(ws * da[j], ws * da[j + 1]);
       }
     }
     *reinterpret_cast<uint4*>(orow + c) = make_uint4(kk[0], kk[1], kk[2], kk[3]);

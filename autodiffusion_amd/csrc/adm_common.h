@@ -64,6 +64,11 @@ __device__ __forceinline__ uint16_t adm_f32_to_h(float f) {
 __device__ __forceinline__ float adm_lo_f32(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float adm_hi_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 #endif
+// two fp32 -> one packed pair (round-to-nearest-even): ONE instruction in either build (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t adm_pack2(float lo, float hi) {
+  const adm_h2 v = {(adm_elem_t)lo, (adm_elem_t)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
 // the matrix-core products of the element type (A, B fragments as adm_h8 / 4 x 16 bits; fp32 accumulators)
 __device__ __forceinline__ f32x4 adm_mfma_16x16x32(adm_h8 a, adm_h8 b, f32x4 c, int, int, int) {
 #ifdef ADM_ACT_F16

@@ -351,7 +351,7 @@ conv_kernel(const ConvK p) {
         adm_f32x2_t t = {adm_lo_f32(u[j]), adm_hi_f32(u[j])};
         t = __builtin_elementwise_fma(adm_f32x2_t{a8[2 * j], a8[2 * j + 1]}, t, adm_f32x2_t{b8[2 * j], b8[2 * j + 1]});
         if constexpr (PRO == 2) t = adm_silu2(t);
-        const uint32_t pk = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
+        const uint32_t pk = adm_pack2(t.x, t.y);
         u[j] = valid ? pk : 0u;
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
@@ -627,8 +627,8 @@ conv_kernel(const ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           uint2 o;
-          o.x = (uint32_t)adm_f32_to_h(acc[i][j][0]) | ((uint32_t)adm_f32_to_h(acc[i][j][1]) << 16);
-          o.y = (uint32_t)adm_f32_to_h(acc[i][j][2]) | ((uint32_t)adm_f32_to_h(acc[i][j][3]) << 16);
+          o.x = adm_pack2(acc[i][j][0], acc[i][j][1]);
+          o.y = adm_pack2(acc[i][j][2], acc[i][j][3]);
           *reinterpret_cast<uint2*>(stg + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
         }
       }
@@ -693,7 +693,7 @@ conv_kernel(const ConvK p) {
             for (int q = 0; q < 4; ++q) {
               const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])} +
                               f32x2{adm_lo_f32(r4[q]), adm_hi_f32(r4[q])};
-              a4[q] = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
+              a4[q] = adm_pack2(t.x, t.y);
             }
             v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
           }
@@ -904,7 +904,7 @@ conv32_kernel(const ConvK p) {
         lo = a8[2 * j] * lo + b8[2 * j];
         hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
         if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-        const uint32_t pk = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
+        const uint32_t pk = adm_pack2(lo, hi);
         u[j] = valid ? pk : 0u;
       }
       v = make_uint4(u[0], u[1], u[2], u[3]);
@@ -986,8 +986,8 @@ conv32_kernel(const ConvK p) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             uint2 o;
-            o.x = (uint32_t)adm_f32_to_h(acc[i][j][4 * g + 0] + bs.x) | ((uint32_t)adm_f32_to_h(acc[i][j][4 * g + 1] + bs.y) << 16);
-            o.y = (uint32_t)adm_f32_to_h(acc[i][j][4 * g + 2] + bs.z) | ((uint32_t)adm_f32_to_h(acc[i][j][4 * g + 3] + bs.w) << 16);
+            o.x = adm_pack2(acc[i][j][4 * g + 0] + bs.x, acc[i][j][4 * g + 1] + bs.y);
+            o.y = adm_pack2(acc[i][j][4 * g + 2] + bs.z, acc[i][j][4 * g + 3] + bs.w);
             *reinterpret_cast<uint2*>(smem + (i * 32 + lp) * EROW + ch0 * 2) = o;
           }
         }
@@ -1008,7 +1008,7 @@ conv32_kernel(const ConvK p) {
         for (int q = 0; q < 4; ++q) {
           const float lo = adm_lo_f32(a4[q]) + adm_lo_f32(r4[q]);
           const float hi = adm_hi_f32(a4[q]) + adm_hi_f32(r4[q]);
-          a4[q] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
+          a4[q] = adm_pack2(lo, hi);
         }
         v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
       }
@@ -1107,7 +1107,7 @@ conv_splitk_reduce(const float* __restrict__ ws, int ksplit, const float* __rest
       }
       uint32_t o[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (uint32_t)adm_f32_to_h(v[2 * j]) | ((uint32_t)adm_f32_to_h(v[2 * j + 1]) << 16);
+      for (int j = 0; j < 4; ++j) o[j] = adm_pack2(v[2 * j], v[2 * j + 1]);
       if (res) {   // as the one-pass epilogue: the conv result is rounded to bf16 first, then the residual is added
         const uint4 rv = *reinterpret_cast<const uint4*>(res + e);
         const uint32_t r4[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -1115,7 +1115,7 @@ conv_splitk_reduce(const float* __restrict__ ws, int ksplit, const float* __rest
         for (int j = 0; j < 4; ++j) {
           const float lo = adm_lo_f32(o[j]) + adm_lo_f32(r4[j]);
           const float hi = adm_hi_f32(o[j]) + adm_hi_f32(r4[j]);
-          o[j] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
+          o[j] = adm_pack2(lo, hi);
         }
       }
       *reinterpret_cast<uint4*>(out + e) = make_uint4(o[0], o[1], o[2], o[3]);

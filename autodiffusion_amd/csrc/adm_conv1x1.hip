@@ -129,7 +129,7 @@ conv1x1r_kernel(const Conv1K p) {
             lo = a8[2 * j] * lo + b8[2 * j];
             hi = a8[2 * j + 1] * hi + b8[2 * j + 1];
             if constexpr (PRO == 2) { lo = adm_silu(lo); hi = adm_silu(hi); }
-            w4[j] = (uint32_t)adm_f32_to_h(lo) | ((uint32_t)adm_f32_to_h(hi) << 16);
+            w4[j] = adm_pack2(lo, hi);
           }
           o = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
@@ -220,8 +220,8 @@ conv1x1r_kernel(const Conv1K p) {
             for (int j = 0; j < TN; ++j) {
               const f32x4 v = acc[2 * c + ii][j];
               uint2 o;
-              o.x = (uint32_t)adm_f32_to_h(v[0]) | ((uint32_t)adm_f32_to_h(v[1]) << 16);
-              o.y = (uint32_t)adm_f32_to_h(v[2]) | ((uint32_t)adm_f32_to_h(v[3]) << 16);
+              o.x = adm_pack2(v[0], v[1]);
+              o.y = adm_pack2(v[2], v[3]);
               *reinterpret_cast<uint2*>(wst + (ii * 16 + lc) * WROW + (j * 16 + lq * 4) * 2) = o;
             }
 #pragma unroll
@@ -238,7 +238,7 @@ conv1x1r_kernel(const Conv1K p) {
               for (int e = 0; e < 4; ++e) {
                 const f32x2 t = f32x2{adm_lo_f32(a4[e]), adm_hi_f32(a4[e])} +
                                 f32x2{adm_lo_f32(r4[e]), adm_hi_f32(r4[e])};
-                a4[e] = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
+                a4[e] = adm_pack2(t.x, t.y);
               }
               v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
             }
@@ -287,8 +287,8 @@ conv1x1r_kernel(const Conv1K p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
               uint2 o;
-              o.x = (uint32_t)adm_f32_to_h(acc[i][j][0]) | ((uint32_t)adm_f32_to_h(acc[i][j][1]) << 16);
-              o.y = (uint32_t)adm_f32_to_h(acc[i][j][2]) | ((uint32_t)adm_f32_to_h(acc[i][j][3]) << 16);
+              o.x = adm_pack2(acc[i][j][0], acc[i][j][1]);
+              o.y = adm_pack2(acc[i][j][2], acc[i][j][3]);
               *reinterpret_cast<uint2*>(stg + ((wm * TM + i) * 16 + lc) * EROW + ch0 * 2) = o;
             }
           }
@@ -318,7 +318,7 @@ conv1x1r_kernel(const Conv1K p) {
             for (int q = 0; q < 4; ++q) {
               const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])} +
                               f32x2{adm_lo_f32(r4[q]), adm_hi_f32(r4[q])};
-              a4[q] = (uint32_t)adm_f32_to_h(t.x) | ((uint32_t)adm_f32_to_h(t.y) << 16);
+              a4[q] = adm_pack2(t.x, t.y);
             }
             v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
           }

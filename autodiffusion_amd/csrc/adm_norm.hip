@@ -51,10 +51,10 @@ stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const floa
       }
     }
     uint4 pk;
-    pk.x = adm_f32_to_h(acc[0]) | ((uint32_t)adm_f32_to_h(acc[1]) << 16);
-    pk.y = adm_f32_to_h(acc[2]) | ((uint32_t)adm_f32_to_h(acc[3]) << 16);
-    pk.z = adm_f32_to_h(acc[4]) | ((uint32_t)adm_f32_to_h(acc[5]) << 16);
-    pk.w = adm_f32_to_h(acc[6]) | ((uint32_t)adm_f32_to_h(acc[7]) << 16);
+    pk.x = adm_pack2(acc[0], acc[1]);
+    pk.y = adm_pack2(acc[2], acc[3]);
+    pk.z = adm_pack2(acc[4], acc[5]);
+    pk.w = adm_pack2(acc[6], acc[7]);
     *reinterpret_cast<uint4*>(out + pix * cout + g * 8) = pk;
   }
 }
@@ -247,10 +247,10 @@ resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a
       for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
     }
     uint4 pk;
-    pk.x = adm_f32_to_h(acc[0]) | ((uint32_t)adm_f32_to_h(acc[1]) << 16);
-    pk.y = adm_f32_to_h(acc[2]) | ((uint32_t)adm_f32_to_h(acc[3]) << 16);
-    pk.z = adm_f32_to_h(acc[4]) | ((uint32_t)adm_f32_to_h(acc[5]) << 16);
-    pk.w = adm_f32_to_h(acc[6]) | ((uint32_t)adm_f32_to_h(acc[7]) << 16);
+    pk.x = adm_pack2(acc[0], acc[1]);
+    pk.y = adm_pack2(acc[2], acc[3]);
+    pk.z = adm_pack2(acc[4], acc[5]);
+    pk.w = adm_pack2(acc[6], acc[7]);
     *reinterpret_cast<uint4*>(out + opix * c + g * 8) = pk;
   }
 }

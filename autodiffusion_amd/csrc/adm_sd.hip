@@ -23,10 +23,10 @@ __device__ __forceinline__ void unpack8(const uint4 v, float* f) {
 
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 pk;
-  pk.x = adm_f32_to_h(f[0]) | ((uint32_t)adm_f32_to_h(f[1]) << 16);
-  pk.y = adm_f32_to_h(f[2]) | ((uint32_t)adm_f32_to_h(f[3]) << 16);
-  pk.z = adm_f32_to_h(f[4]) | ((uint32_t)adm_f32_to_h(f[5]) << 16);
-  pk.w = adm_f32_to_h(f[6]) | ((uint32_t)adm_f32_to_h(f[7]) << 16);
+  pk.x = adm_pack2(f[0], f[1]);
+  pk.y = adm_pack2(f[2], f[3]);
+  pk.z = adm_pack2(f[4], f[5]);
+  pk.w = adm_pack2(f[6], f[7]);
   return pk;
 }
 
