@@ -26,19 +26,20 @@ SHAPES = [
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load("f16" if os.environ.get("ADM_TIMING_F16") else "bf16")
     fn = lib.adm_conv_timing_read
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     for name, n, hw, cin, cout, taps, prologue, res in SHAPES:
         k = 3 if taps == 9 else 1
-        x0 = torch.randn(n, hw, hw, cin, device=DEV).to(torch.bfloat16)
+        DT = torch.float16 if os.environ.get("ADM_TIMING_F16") else torch.bfloat16   # with ADM_HIP_LIB_F16 = the f16 timing build
+        x0 = torch.randn(n, hw, hw, cin, device=DEV).to(DT)
         w = torch.randn(cout, cin, k, k, device=DEV) * (cin * taps) ** -0.5
-        wp = ops.pack_conv_weight(w)
+        wp = ops.pack_conv_weight(w, DT)
         b = torch.randn(cout, device=DEV) * 0.1
         aff = (1 + 0.1 * torch.randn(n, cin, device=DEV), 0.1 * torch.randn(n, cin, device=DEV)) if prologue else None
-        r = torch.randn(n, hw, hw, cout, device=DEV).to(torch.bfloat16) if res else None
-        out = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
+        r = torch.randn(n, hw, hw, cout, device=DEV).to(DT) if res else None
+        out = torch.empty(n, hw, hw, cout, dtype=DT, device=DEV)
         for _ in range(3):
             ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
         torch.cuda.synchronize()
