@@ -20,8 +20,9 @@ def setup_dist():
     os.environ.setdefault("MASTER_PORT", "12345")
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+    # ADM_DIST_BACKEND=gloo: rehearse several ranks on ONE GPU (RCCL refuses two ranks per device); real runs use nccl = RCCL
+    backend = os.environ.get("ADM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
         torch.cuda.set_device(dev())
     dist.init_process_group(backend=backend, init_method="env://")
 

@@ -113,15 +113,18 @@ class ActivationAccumulator:
             return self.n, self.s1, self.s2
         world = dist.get_world_size(group)
         d = self.dim
+        # RCCL gathers device buffers over xGMI; gloo (CPU tests, one-GPU rehearsals) gathers host copies
+        comm_dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
         mine = torch.empty(1 + d + d * d, dtype=torch.float64, device=self.device)
         mine[0] = float(self.n)
         mine[1:1 + d] = self.s1
         mine[1 + d:] = self.s2.reshape(-1)
+        mine = mine.to(comm_dev)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
-        tot = parts[0]
+        tot = parts[0].to(self.device)
         for r in range(1, world):
-            tot = tot + parts[r]
+            tot = tot + parts[r].to(self.device)
         n = int(round(float(tot[0].item())))
         return n, tot[1:1 + d].contiguous(), tot[1 + d:].reshape(d, d).contiguous()
 
