@@ -253,7 +253,8 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
          out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
-    x0 (| x1): bf16 NHWC.  Returns bf16 NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].
+    x0 (| x1): 16-bit NHWC (bf16, or fp16 for an fp16-torso model: the library is picked by x0's dtype).  Returns the same
+    type NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].  ksplit > 1: split-K schedule for small batches (see splitk_for).
     in_up / res_up: x0 / res are at half resolution and are read through a virtual nearest-neighbour 2x upsample
     (the output is [n, 2h, 2w, cout]): ResBlock(up=True) without materialising the upsampled tensors.
     """
@@ -290,7 +291,7 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
         w_packed32 = None  # the 32x32x16 kernel does not take the virtual upsample
     if variant == 0:
         variant = lib.adm_conv_pick_variant(C.byref(a))  # the library's own rule (incl. the resident-tile 1x1 kernel)
-        if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw:
+        if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw and ksplit <= 1:
             variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
         a.variant = variant
     fused = None
