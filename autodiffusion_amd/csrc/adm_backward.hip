@@ -81,43 +81,55 @@ gn_bwd_partial_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
   }
 }
 
-// grid (n): k1, k0 per (image, channel)
+// grid (n, 4): k1, k0 per (image, channel); a block takes 8 of the 32 groups, half a wave per group.
+// The launch is dependent-latency bound (a few hundred 8-byte loads per group), so the work of a group is spread over
+// 32 lanes with four loads in flight each: one thread-quarter per group and one load in flight took 52 us per call,
+// 2.9 % of the guided step (profiles/r02/bench_guided_b256_b_kernel_stats.csv).
 __global__ void __launch_bounds__(256)
 gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ aa, const float* __restrict__ stats,
                        float* __restrict__ k1, float* __restrict__ k0, int c, int hw, int slabs) {
-  __shared__ float gk1[32], gk0[32];
   const int img = blockIdx.x;
   const int cpg = c / 32;
-  const int grp = threadIdx.x / 8, sub = threadIdx.x % 8;
+  const int grp = blockIdx.y * 8 + threadIdx.x / 32, sub = threadIdx.x % 32;
   const float mean = stats[((long long)img * 32 + grp) * 2 + 0], rstd = stats[((long long)img * 32 + grp) * 2 + 1];
-  // a latency-bound launch: no divisions in the loop (1/rstd is applied to the sum), 8-byte loads
+  const float* pb = partial + ((long long)img * slabs * c + (long long)grp * cpg) * 2;
+  const float* ab = aa + (long long)img * c + grp * cpg;
+  const int items = slabs * cpg;     // item i = (slab i / cpg, channel-in-group i % cpg)
   double s1 = 0.0, s2 = 0.0;
-  int sl = sub / cpg, j = sub % cpg;
-  for (int i = sub; i < slabs * cpg; i += 8) {
-    const int ch = grp * cpg + j;
-    const float2 v = *reinterpret_cast<const float2*>(partial + ((((long long)img * slabs + sl) * c) + ch) * 2);
-    const double a = (double)aa[(long long)img * c + ch];
-    s1 += a * (double)v.x;
-    s2 += a * ((double)v.y - (double)mean * (double)v.x);
-    j += 8;
-    while (j >= cpg) { j -= cpg; ++sl; }
+  auto at = [&](int i, float2& v, float& a) {
+    const int sl = i / cpg, j = i - sl * cpg;
+    v = *reinterpret_cast<const float2*>(pb + ((long long)sl * c + j) * 2);
+    a = ab[j];
+  };
+  auto acc = [&](const float2& v, float a) {
+    s1 += (double)a * (double)v.x;
+    s2 += (double)a * ((double)v.y - (double)mean * (double)v.x);
+  };
+  int i = sub;
+  for (; i + 96 < items; i += 128) {
+    float2 v0, v1, v2, v3;
+    float a0, a1, a2, a3;
+    at(i, v0, a0); at(i + 32, v1, a1); at(i + 64, v2, a2); at(i + 96, v3, a3);
+    acc(v0, a0); acc(v1, a1); acc(v2, a2); acc(v3, a3);
+  }
+  for (; i < items; i += 32) {
+    float2 v;
+    float a;
+    at(i, v, a);
+    acc(v, a);
   }
   s1 /= (double)rstd;
 #pragma unroll
-  for (int off = 4; off >= 1; off >>= 1) {
+  for (int off = 16; off >= 1; off >>= 1) {
     s1 += __shfl_xor(s1, off);
     s2 += __shfl_xor(s2, off);
   }
-  if (sub == 0) {
-    const double m = (double)cpg * (double)hw;
-    const double kk1 = -(double)rstd * (double)rstd * s2 / m;
-    gk1[grp] = (float)kk1;
-    gk0[grp] = (float)(-(double)rstd * s1 / m - (double)mean * kk1);
-  }
-  __syncthreads();
-  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-    k1[(long long)img * c + ch] = gk1[ch / cpg];
-    k0[(long long)img * c + ch] = gk0[ch / cpg];
+  const double m = (double)cpg * (double)hw;
+  const double kk1 = -(double)rstd * (double)rstd * s2 / m;
+  const float f1 = (float)kk1, f0 = (float)(-(double)rstd * s1 / m - (double)mean * kk1);
+  for (int j = sub; j < cpg; j += 32) {
+    k1[(long long)img * c + grp * cpg + j] = f1;
+    k0[(long long)img * c + grp * cpg + j] = f0;
   }
 }
 
@@ -402,7 +414,7 @@ extern "C" int adm_gn_bwd_finalize(const float* partial, const float* aff_a, con
                                    int n, int c, int hw, int slabs, void* stream) {
   ADM_REQUIRE(partial && aff_a && stats && k1 && k0, ADM_E_ARG, "adm_gn_bwd_finalize: null pointer");
   ADM_REQUIRE(n > 0 && c % 32 == 0 && hw > 0 && slabs > 0, ADM_E_SHAPE, "adm_gn_bwd_finalize: bad shape");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, aff_a, stats, k1, k0,
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, partial, aff_a, stats, k1, k0,
                      c, hw, slabs);
   return adm_check_launch("adm_gn_bwd_finalize");
 }

@@ -90,6 +90,100 @@ linear_kernel(const float* __restrict__ in, const float* __restrict__ w, const f
 }
 
 
+// Many rows, K a multiple of 16 (every ResBlock's emb_layers at batch 256: n = 256, k = 768, o = 33 792): the same fp32
+// product on the matrix pipe, v_mfma_f32_16x16x4_f32 -- exact fp32 multiplies with fp32 accumulation, so the numerics stay
+// those of the tile kernel above up to the summation order.  A block is 4 waves x 64 rows by 32 output columns; both
+// operands are K-contiguous, so a lane fetches 16 bytes of its row (4 consecutive k) straight from global memory and feeds
+// element j to the j-th of 4 MFMAs (the k order inside a 16-deep step is permuted the same way for both operands); no LDS,
+// the four waves share the weight fragments through the L1, the activations (n x k) stay in L2.  The tile kernel reached
+// 50 TFLOP/s on that shape (264 us average, 1.2 % of the guided batch, profiles/r02/bench_guided_b256_b_kernel_stats.csv).
+typedef __attribute__((ext_vector_type(4))) float lin_f32x4;
+
+template <bool SILU, int KU>   // KU float4 per operand row and step: 16 * KU k-values per step (k % (16 * KU) == 0)
+__global__ void __launch_bounds__(256)
+linear_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                   const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
+                   int n, int k, int o) {
+  constexpr int TM = 4, TN = 2, KSTEP = 16 * KU;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  const int row0 = (blockIdx.y * 4 + wave) * (TM * 16), col0 = blockIdx.x * (TN * 16);
+  if (row0 >= n) return;   // wave-uniform; no barriers in this kernel
+  const float* ap[TM];
+  const float* bp[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ap[i] = in + (long long)min(row0 + i * 16 + lc, n - 1) * k + lq * 4;   // clamped rows are not stored
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bp[j] = w + (long long)min(col0 + j * 16 + lc, o - 1) * k + lq * 4;
+  lin_f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = lin_f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 a[KU][TM], b[KU][TN], an[KU][TM], bn[KU][TN];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[u][i] = *reinterpret_cast<const float4*>(ap[i] + u * 16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[u][j] = *reinterpret_cast<const float4*>(bp[j] + u * 16);
+  }
+  for (int k0 = 0; k0 < k; k0 += KSTEP) {
+    const int kn = k0 + KSTEP < k ? k0 + KSTEP : k0;   // the last step re-reads its own operands (unused)
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) an[u][i] = *reinterpret_cast<const float4*>(ap[i] + kn + u * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bn[u][j] = *reinterpret_cast<const float4*>(bp[j] + kn + u * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (SILU) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          a[u][i].x = adm_silu(a[u][i].x); a[u][i].y = adm_silu(a[u][i].y);
+          a[u][i].z = adm_silu(a[u][i].z); a[u][i].w = adm_silu(a[u][i].w);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[u][i].x : e == 1 ? a[u][i].y : e == 2 ? a[u][i].z : a[u][i].w;
+            const float bv = e == 0 ? b[u][j].x : e == 1 ? b[u][j].y : e == 2 ? b[u][j].z : b[u][j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[u][i] = an[u][i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[u][j] = bn[u][j];
+    }
+  }
+  // accumulator layout: lane holds column lc, rows 4 * lq + e
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 16 + lc;
+    if (col >= o) continue;
+    const float bj = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + i * 16 + lq * 4 + e;
+        if (row >= n) continue;
+        float v = acc[i][j][e] + bj;
+        if (table) v += table[(long long)idx[row] * o + col];
+        out[(long long)row * o + col] = v;
+      }
+  }
+}
+
 // Few rows (n <= 64: the Stable-Diffusion UNet evaluates 12 latents): a GEMV-shaped pass.  The 64 x 64 tile kernel above
 // leaves most of its rows empty and crawls through K behind two barriers per 16-deep step; here a block keeps 16 input rows
 // (activation applied) in LDS, each wave streams whole weight rows with 16-byte lanes (every weight is read once per 16
@@ -189,6 +283,13 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
     dim3 g((o + 4 * LS_CPW - 1) / (4 * LS_CPW), (n + LS_ROWS - 1) / LS_ROWS);
     if (silu_in) hipLaunchKernelGGL((linear_small_kernel<true>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
     else hipLaunchKernelGGL((linear_small_kernel<false>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
+    return adm_check_launch("adm_linear_f32");
+  }
+  if (k % 16 == 0 && adm_aligned16(w) && adm_aligned16(in)) {
+    dim3 g((o + 31) / 32, (n + 255) / 256);
+    // 16 k-values per step: 32- and 64-deep steps (KU = 2, 4) measured 15 % slower (205 vs 179 us on 256 x 768 -> 33 792)
+    if (silu_in) hipLaunchKernelGGL((linear_mfma_kernel<true, 1>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+    else hipLaunchKernelGGL((linear_mfma_kernel<false, 1>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
     return adm_check_launch("adm_linear_f32");
   }
   dim3 grid((o + LT - 1) / LT, (n + LT - 1) / LT);

@@ -114,7 +114,8 @@ def test_timestep_embedding(ops):
 
 
 @pytest.mark.parametrize("n,k,o", [(2, 128, 64), (5, 768, 1000), (256, 768, 1536), (3, 32, 128), (12, 1280, 21120), (48, 1280, 333),
-                                   (17, 320, 1280), (1, 4, 1), (65, 128, 96), (7, 30, 50)])
+                                   (17, 320, 1280), (1, 4, 1), (65, 128, 96), (7, 30, 50), (70, 48, 50), (130, 16, 33),
+                                   (300, 64, 40), (129, 30, 20)])
 def test_linear_f32(ops, n, k, o):
     x, w, b = rnd((n, k), 1), rnd((o, k), 2, k ** -0.5), rnd((o,), 3, 0.1)
     tab, idx = rnd((10, o), 4), torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(5))

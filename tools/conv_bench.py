@@ -3,6 +3,7 @@
 Prints TFLOP/s (algorithmic 2*M*Cout*Cin*taps) per shape; used to iterate on csrc/adm_conv.hip."""
 import os
 import sys
+import time
 
 import torch
 
@@ -51,8 +52,10 @@ def main():
         aff = (1 + 0.1 * torch.randn(n, cin, device=DEV), 0.1 * torch.randn(n, cin, device=DEV)) if prologue else None
         r = torch.randn(n, hw, hw, cout, device=DEV).to(torch.bfloat16) if res else None
         out = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=DEV)
-        for _ in range(2):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.03:   # warm up by time: the clocks ramp for some milliseconds after an idle spell
             ops.conv(x0, wp, b, cout, taps, x1=x1, aff=aff, silu=(prologue == 2), res=r, variant=variant, out=out, w_packed32=wp32)
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
