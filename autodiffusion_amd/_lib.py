@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")
 # the same kernels built with IEEE half as the 16-bit element type (csrc/adm_common.h, -DADM_ACT_F16): the reference's own
 # torso precision (use_fp16=True); selected per tensor dtype by ops.py, per model by `torso="fp16"` / ADM_TORSO=fp16
 LIB_PATH_F16 = os.environ.get("ADM_HIP_LIB_F16") or os.path.join(_HERE, "libadm_hip_f16.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class AdmError(RuntimeError):
@@ -29,6 +29,13 @@ class StepCoefs(C.Structure):
         ("eta", C.c_float), ("nonzero", C.c_int32), ("learned_range", C.c_int32),
         ("predict_xstart", C.c_int32), ("clip_denoised", C.c_int32),
     ]
+
+
+class Conv2dArgs(C.Structure):
+    """struct adm_conv2d_args (include/adm_hip.h)."""
+    _fields_ = [("in_", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p)] + [
+        (k, C.c_int32) for k in ("n", "h", "w_in", "cin_pad", "in_stride", "cout", "out_stride", "kh", "kw", "stride",
+                                 "pad_h", "pad_w", "relu")]
 
 
 class ConvArgs(C.Structure):
@@ -93,6 +100,11 @@ SIGNATURES = {
     "adm_sd_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(SdStepCoefs), _P]),
     "adm_dpm_step": (_I, [_P, _P, _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _F, _P]),
     "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
+    "adm_conv2d": (_I, [C.POINTER(Conv2dArgs), _P]),
+    "adm_pack_conv2d_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "adm_pool2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "adm_global_avgpool_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "adm_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
 }
 
 _libs = {}

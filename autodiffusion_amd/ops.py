@@ -460,3 +460,92 @@ def pack_conv_weight_bwd(w, dtype=BF16):
     out = torch.empty((elems,), dtype=dtype, device=w.device)
     check(lib.adm_pack_conv_weight_bwd(_ptr(w32), _ptr(out), cout, cin, taps, _stream()), "adm_pack_conv_weight_bwd")
     return out
+
+
+# ------------------------------------------------------------------ Inception layers (csrc/adm_convg.hip)
+def _nhwc_view(t: torch.Tensor, name: str):
+    """(data pointer, channel stride) of a 4-D NHWC tensor or of a CHANNEL SLICE of one (t[..., a:b]): pixels dense,
+    channels contiguous."""
+    if t.dim() != 4 or not t.is_cuda:
+        raise AdmError(f"{name}: expected a 4-D NHWC device tensor")
+    n, h, w, c = t.shape
+    cs = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != w * cs or t.stride(0) != h * w * cs or cs < c:
+        raise AdmError(f"{name}: not an NHWC tensor / channel slice (strides {t.stride()})")
+    if t.device.index != torch.cuda.current_device():
+        raise AdmError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}")
+    return t.data_ptr(), cs
+
+
+def pack_conv2d_weight(w, scale=None, dtype=F16):
+    """fp32 [cout, cin, kh, kw] (x scale[cout]: a folded BatchNorm) -> the [cout][kh*kw][cin_pad] layout of adm_conv2d."""
+    cout, cin, kh, kw = w.shape
+    cin_pad = (cin + 31) // 32 * 32
+    lib = _lib.load("f16" if dtype == F16 else "bf16")
+    w32 = w.detach().to(torch.float32).contiguous()
+    s32 = None if scale is None else scale.detach().to(torch.float32).contiguous()
+    out = torch.empty((cout, kh * kw, cin_pad), dtype=dtype, device=w.device)
+    check(lib.adm_pack_conv2d_weight(_ptr(w32), _ptr(s32), _ptr(out), cout, cin, kh, kw, cin_pad, _stream()),
+          "adm_pack_conv2d_weight")
+    return out
+
+
+def conv2d(x, w_packed, bias, kh: int, kw: int, stride: int = 1, pad=(0, 0), relu: bool = True, out=None):
+    """General NHWC convolution on the matrix cores.  x: [N,H,W,Cs] (or a channel slice) whose first cin_pad =
+    w_packed.shape[2] channels are read; out: [N,OH,OW,cout] tensor or channel slice of a concatenated tensor."""
+    n, h, w, _ = x.shape
+    cout, taps, cin_pad = w_packed.shape
+    if taps != kh * kw:
+        raise AdmError(f"conv2d: packed weight has {taps} taps, kernel is {kh}x{kw}")
+    if x.shape[3] < cin_pad:
+        raise AdmError(f"conv2d: the input holds {x.shape[3]} channels, the packed weight reads {cin_pad} (pad the tensor with zeros)")
+    oh, ow = (h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n, oh, ow, cout), dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != (n, oh, ow, cout) or out.dtype != x.dtype or w_packed.dtype != x.dtype:
+        raise AdmError(f"conv2d: output {tuple(out.shape)} / dtypes do not match ({n}, {oh}, {ow}, {cout}) {x.dtype}")
+    a = _lib.Conv2dArgs()
+    a.in_, a.in_stride = _nhwc_view(x, "x")
+    a.out, a.out_stride = _nhwc_view(out, "out")
+    a.w, a.bias = _ptr(w_packed, x.dtype, "w_packed"), _ptr(bias, torch.float32, "bias")
+    a.n, a.h, a.w_in, a.cin_pad, a.cout = n, h, w, cin_pad, cout
+    a.kh, a.kw, a.stride, a.pad_h, a.pad_w, a.relu = kh, kw, stride, pad[0], pad[1], int(relu)
+    check(_L(x).adm_conv2d(C.byref(a), _stream()), "adm_conv2d")
+    return out
+
+
+def pool2d(x, k: int, stride: int, pad: int, mode: str, out=None):
+    """mode "max" (F.max_pool2d) or "avg" (F.avg_pool2d(count_include_pad=False)) over NHWC; out may be a channel slice."""
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty((n, oh, ow, c), dtype=x.dtype, device=x.device)
+    if tuple(out.shape) != (n, oh, ow, c) or out.dtype != x.dtype:
+        raise AdmError(f"pool2d: output {tuple(out.shape)} does not match ({n}, {oh}, {ow}, {c})")
+    pi, si = _nhwc_view(x, "x")
+    po, so = _nhwc_view(out, "out")
+    check(_L(x).adm_pool2d(pi, po, n, h, w, c, si, so, k, stride, pad, {"max": 0, "avg": 1}[mode], _stream()), "adm_pool2d")
+    return out
+
+
+def global_avgpool_f32(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(_L(x).adm_global_avgpool_f32(_ptr(x, x.dtype, "x"), _ptr(out), n, h * w, c, _stream()), "adm_global_avgpool_f32")
+    return out
+
+
+def resize_bilinear(images, oh: int, ow: int, cpad: int, layout: str, half_pixel: bool, scale: float, shift: float, dtype=F16):
+    """3-channel images -> [N, oh, ow, cpad] 16-bit NHWC (channels 3.. zero), value * scale + shift.
+    layout "u8_nhwc" | "f32_nchw" | "f32_nhwc"."""
+    kind = {"u8_nhwc": 0, "f32_nchw": 1, "f32_nhwc": 2}[layout]
+    want = torch.uint8 if kind == 0 else torch.float32
+    if images.dim() != 4 or images.shape[1 if kind == 1 else 3] != 3:
+        raise AdmError(f"resize_bilinear: expected 3-channel {layout} images, got {tuple(images.shape)}")
+    n = images.shape[0]
+    h, w = (images.shape[2], images.shape[3]) if kind == 1 else (images.shape[1], images.shape[2])
+    out = torch.empty((n, oh, ow, cpad), dtype=dtype, device=images.device)
+    lib = _lib.load("f16" if dtype == F16 else "bf16")
+    check(lib.adm_resize_bilinear(_ptr(images, want, "images"), _ptr(out), n, h, w, oh, ow, cpad, kind, int(half_pixel),
+                                  float(scale), float(shift), _stream()), "adm_resize_bilinear")
+    return out

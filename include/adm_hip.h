@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 3   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws */
+#define ADM_ABI_VERSION 4   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -297,6 +297,36 @@ int adm_pack_conv_weight_bwd(const float* w, adm_bf16* out, int cout, int cin, i
  * batch of fp32 activations [n][d] (np.mean / np.cov, evaluations/evaluator_v1.py:218-221).
  * s1 fp64 [d], s2 fp64 [d][d], zero-initialised by the caller before the first batch.        */
 int adm_fid_accumulate(const float* acts, double* s1, double* s2, int n, int d, void* stream);
+
+/* ---------------------------------------------------------------- Inception-v3 pool3 features (K12, A11 compute_activations)
+ * The layers of the FID feature extractor the reference runs through third-party code: a frozen TensorFlow graph
+ * (evaluations/evaluator_v1.py:263-269, 665-679) / pytorch_fid.inception.InceptionV3 (Stable Diffusion
+ * scripts/search_ea.py:95-127, 171-182).  BasicConv2d = conv(no bias) + BatchNorm(eps 1e-3) + ReLU: the caller folds the
+ * BatchNorm scale into the packed weights and passes the shift as `bias`.
+ *
+ * adm_conv2d: general 2-D convolution, NHWC.  `in` = [n][h][w_in][in_stride] elements of which channels [0, cin_pad) are
+ * read (cin_pad % 32 == 0; channels beyond the layer's real cin must hold zeros or meet zero weights); `w` from
+ * adm_pack_conv2d_weight = [cout][kh*kw][cin_pad]; `out` = [n][oh][ow][out_stride] of which channels [0, cout) are written
+ * -- point it at a channel slice of a concatenated tensor (cout % 4 == 0, 8-byte aligned).  oh = (h + 2 pad_h - kh)/stride + 1. */
+typedef struct adm_conv2d_args {
+  const adm_bf16* in; const adm_bf16* w; const float* bias; adm_bf16* out;
+  int32_t n, h, w_in, cin_pad, in_stride, cout, out_stride, kh, kw, stride, pad_h, pad_w;
+  int32_t relu;      /* 1: max(x, 0) after the bias */
+} adm_conv2d_args;
+int adm_conv2d(const adm_conv2d_args* args, void* stream);
+/* fp32 [cout][cin][kh][kw] (torch Conv2d.weight), optionally times scale[cout], -> the 16-bit layout above */
+int adm_pack_conv2d_weight(const float* w, const float* scale, adm_bf16* out, int cout, int cin, int kh, int kw, int cin_pad,
+                           void* stream);
+/* k x k pooling of a channel slice (c % 8 == 0).  mode 0: max (F.max_pool2d), 1: average over the taps inside the image
+ * (F.avg_pool2d(count_include_pad=False), the FID variant of the Inception blocks)                                        */
+int adm_pool2d(const adm_bf16* in, adm_bf16* out, int n, int h, int w, int c, int in_stride, int out_stride, int k, int stride,
+               int pad, int mode, void* stream);
+/* mean over the hw pixels: [n][hw][c] -> fp32 [n][c] (the pool3 features)                                                 */
+int adm_global_avgpool_f32(const adm_bf16* in, float* out, int n, int hw, int c, void* stream);
+/* 3-channel images -> [n][oh][ow][cpad] (channels 3.. zero), value * scale + shift.  kind 0: uint8 NHWC, 1: fp32 NCHW,
+ * 2: fp32 NHWC.  half_pixel 1: torch bilinear, align_corners=False (pytorch_fid); 0: TensorFlow-1 ResizeBilinear.          */
+int adm_resize_bilinear(const void* in, adm_bf16* out, int n, int h, int w, int oh, int ow, int cpad, int kind, int half_pixel,
+                        float scale, float shift, void* stream);
 
 #ifdef __cplusplus
 }

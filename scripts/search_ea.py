@@ -6,10 +6,11 @@ search_uncondition_model.py (``--without_classifier True``): ``--time_step 4 --m
 --population_num 50 --mutation_num 25 --crossover_num 15 --m_prob 0.25 --use_ddim_init_x True`` ...
 Result lines ("epoch = i : top k result", "No.j [..] fid = ..") go to ``<save_dir>/log.txt`` unchanged.
 
-What this build needs from the user that the reference downloaded: the Inception pool3 feature extractor.
-``--features pkg.module:factory`` names a callable ``factory(device) -> (features, dim)`` where
-``features(uint8 NHWC device batch) -> fp32 [B, dim]``; ``--ref_path`` is an .npz with ``mu``, ``sigma``
-(written from the reference's pickled FIDStatistics).  ``--use_graph True`` replays each UNet evaluation / guidance gradient as a captured hipGraph (batches <= ~100 are
+FID features: by default the bundled HIP Inception-v3 pool3 extractor (autodiffusion_amd/inception.py) with the weights
+named by ``--inception_path`` (the pt_inception-2015-12-05 state_dict the reference's evaluator stack downloads; it is
+not in this image -- without it the extractor runs on random weights and says so).  ``--features pkg.module:factory``
+swaps in any callable ``factory(device) -> (features, dim)`` with ``features(uint8 NHWC device batch) -> fp32 [B, dim]``.
+``--ref_path`` is an .npz with ``mu``, ``sigma`` (written from the reference's pickled FIDStatistics).  ``--use_graph True`` replays each UNet evaluation / guidance gradient as a captured hipGraph (batches <= ~100 are
 bound by the host launch rate otherwise).  ``--population_parallel True`` shards whole
 candidates over ranks; otherwise every candidate's images are sharded and the statistics pooled.
 
@@ -43,7 +44,7 @@ def create_argparser():
         time_step=100, seed=0, deterministic=False, local_rank=0, max_epochs=20, select_num=10, population_num=50,
         m_prob=0.1, crossover_num=25, mutation_num=35, classifier_path="", classifier_scale=1.0, max_fid=48.0,
         thres=0.2, use_ddim_init_x=False, search_space="", ref_path="", MASTER_PORT="12344", init_x="",
-        without_classifier=False, features="", population_parallel=False, fid_on_device=False, use_graph=False,
+        without_classifier=False, features="", inception_path="", inception_input="tf1", population_parallel=False, fid_on_device=False, use_graph=False,
         index_step=None, max_prun=0.0, min_prun=0.0,
     )
     defaults.update(model_and_diffusion_defaults())
@@ -93,10 +94,12 @@ def main(argv=None):
             classifier.load_state_dict(dist_util.load_state_dict(args.classifier_path, map_location="cpu"))
         else:
             classifier.randomize_(4321)
-    if not args.features:
-        raise SystemExit("--features pkg.module:factory is required (the Inception pool3 extractor is not bundled)")
-    mod, fn = args.features.split(":")
-    features, dim = getattr(importlib.import_module(mod), fn)(dist_util.dev())
+    if args.features:
+        mod, fn = args.features.split(":")
+        features, dim = getattr(importlib.import_module(mod), fn)(dist_util.dev())
+    else:
+        from autodiffusion_amd.inception import pool3_features
+        features, dim = pool3_features(dist_util.dev(), args.inception_path, args.inception_input)
     search_space = build_search_space(args, diffusion)
     if search_space is not None:
         logger.log("search space: " + str(search_space))
