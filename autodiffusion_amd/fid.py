@@ -156,3 +156,42 @@ def cal_fid(batches, batch_size, evaluator, ref_stats, ref_stats_spatial=None):
     acts = evaluator.compute_activations(batches, batch_size)
     pool = acts[0] if isinstance(acts, (tuple, list)) else acts
     return compute_statistics(np.asarray(pool)).frechet_distance(ref_stats)
+
+
+# ------------------------------------------------------------------ Stable-Diffusion search driver's FID helpers
+# Same names, arguments and results as the functions of the reference's SD driver (Stable Diffusion scripts/search_ea.py:
+# get_activations :95-127, calculate_activation_statistics :129-134, calculate_frechet_distance :136-169, calculate_fid
+# :171-182), with ``model`` = autodiffusion_amd.inception.InceptionV3 (the HIP port of pytorch_fid's extractor).
+def get_activations(data, model, batch_size=50, dims=2048, device="cuda", num_workers=1):
+    """data: float tensor [N, 3, H, W] in [0, 1] -> numpy [N, dims] (float64 array as in the reference)."""
+    model.eval()
+    if batch_size > data.shape[0]:
+        print(("Warning: batch size is bigger than the data size. "
+               "Setting batch size to data size"))
+        batch_size = data.shape[0]
+    pred_arr = np.empty((data.shape[0], dims))
+    for i in range(0, data.shape[0], batch_size):
+        pred = model(data[i:i + batch_size].to(device))[0]
+        if pred.size(2) != 1 or pred.size(3) != 1:
+            pred = pred.mean((2, 3), keepdim=True)     # adaptive_avg_pool2d(pred, (1, 1))
+        pred_arr[i:i + pred.shape[0]] = pred.squeeze(3).squeeze(2).cpu().numpy()
+    return pred_arr
+
+
+def calculate_activation_statistics(datas, model, batch_size=50, dims=2048, device="cuda", num_workers=1):
+    act = get_activations(datas, model, batch_size, dims, device, num_workers)
+    return np.mean(act, axis=0), np.cov(act, rowvar=False)
+
+
+def calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    return FIDStatistics(mu1, sigma1).frechet_distance(FIDStatistics(mu2, sigma2), eps=eps)
+
+
+def calculate_fid(data1, ref_mu, ref_sigma, batch_size, device, dims, num_workers=1, model=None):
+    """The reference builds ``InceptionV3([block_idx]).to(device)`` per call (pytorch_fid fetches its weights); pass the
+    loaded HIP extractor as ``model`` -- without it a fresh one with RANDOM weights is built and says so."""
+    from .inception import InceptionV3
+    if model is None:
+        model = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]]).to(device)
+    m1, s1 = calculate_activation_statistics(data1, model, batch_size, dims, device, num_workers)
+    return calculate_frechet_distance(m1, s1, ref_mu, ref_sigma)

@@ -187,3 +187,26 @@ def test_fid_of_device_features_against_host_formula(nets):
     got = acc.statistics().frechet_distance(FIDStatistics(mu, sig))
     want = ofid.frechet_distance(*ofid.statistics(fa.double().cpu().numpy()), mu, sig)
     assert abs(got - want) <= 1e-6 * max(1.0, abs(want))
+
+
+def test_sd_driver_fid_helpers_parity_unpinned(nets):
+    """calculate_fid of the Stable-Diffusion search driver (scripts/search_ea.py:95-182) over the HIP extractor, against
+    the same statistics taken from the CPU restatement's activations (dims 2048 and the 192-d block-1 features)."""
+    oi, p, InceptionV3 = nets
+    from autodiffusion_amd import fid
+    from oracle import fid as ofid
+    x = torch.rand((10, 3, 48, 48), generator=torch.Generator().manual_seed(14))
+    for dims, blk in ((2048, 3), (192, 1)):
+        m = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]]).to(DEV)
+        m.load_state_dict(p)
+        acts = fid.get_activations(x, m, batch_size=4, dims=dims, device=DEV)
+        with torch.no_grad():
+            ref = oi.forward(p, oi.prepare(x, "pt"), upto=blk)[blk].mean((2, 3)).double().numpy()
+        assert acts.shape == (10, dims) and acts.dtype == np.float64
+        assert np.linalg.norm(acts - ref) <= 5e-3 * np.linalg.norm(ref)
+        rng = np.random.RandomState(dims)
+        a = rng.randn(dims, dims) / np.sqrt(dims)
+        rmu, rsig = rng.randn(dims) * 0.1, a @ a.T + 0.05 * np.eye(dims)
+        got = fid.calculate_fid(x, rmu, rsig, 4, DEV, dims, model=m)
+        want = ofid.frechet_distance(*ofid.statistics(acts), rmu, rsig)
+        assert abs(got - want) <= 1e-8 * max(1.0, abs(want))
