@@ -252,6 +252,10 @@ def main():
                          "then come from one extra eager batch after the timed region")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for real multi-GPU runs; gloo only to rehearse N ranks on one GPU")
+    ap.add_argument("--with-fid", action="store_true",
+                    help="also run the FID stage inside every step: HIP Inception-v3 pool3 of the step's uint8 batch (random weights: "
+                         "the checkpoint is not in the image) + the float64 Gram accumulation; the headline line leaves it out "
+                         "(BASELINE's metric is sampling throughput)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--conv-breakdown", action="store_true",
@@ -324,9 +328,20 @@ def main():
     ev.set_candidate(schedule)
     B = args.batch
 
+    fid_net = fid_acc = None
+    if args.with_fid:
+        from autodiffusion_amd.fid import ActivationAccumulator
+        from autodiffusion_amd.inception import InceptionV3
+        fid_net = InceptionV3().to(dev)
+        fid_net.weights_loaded = True     # random weights on purpose (throughput run): no warning
+        fid_acc = ActivationAccumulator(2048, dev)
+
     def one_step(step_idx):
         # deterministic, layout-independent seeding per (step, rank)
-        return ev.sample_batch(B, seed=(1000003 * step_idx + rank))
+        u8 = ev.sample_batch(B, seed=(1000003 * step_idx + rank))
+        if fid_net is not None:
+            fid_acc.add(fid_net.features(u8))
+        return u8
 
     for w in range(args.warmup):
         one_step(-1 - w)
@@ -429,7 +444,8 @@ def main():
             "config": {"workload": wl,
                        "global_batch": world * B, "image_size": size, "sampler_steps": len(schedule),
                        "parallelism": f"dp{world} (image-sharded, no data-path collective)",
-                       "launch": "hipGraph replay" if args.graph else "eager"},
+                       "launch": "hipGraph replay" if args.graph else "eager",
+                       "fid_stage_in_step": bool(args.with_fid)},
             "model_tflops": round(value * gflop_img / 1e3, 1),
             "roofline": roof,
         }
