@@ -51,6 +51,7 @@ gn_bwd_partial_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
     *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(aa + (long long)img * c + ch + 4);
     *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + (long long)img * c + ch);
     *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + (long long)img * c + ch + 4);
+#pragma unroll 2
     for (int p = p_begin + lane; p < p_end; p += lanes) {
       const uint4 xv = *reinterpret_cast<const uint4*>(x + ((long long)img * hw + p) * c + ch);
       const uint4 gv = *reinterpret_cast<const uint4*>(dy + src_pixel(dy_mode, img, p / w, p % w, h, w) * c + ch);
@@ -133,38 +134,49 @@ gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restric
   }
 }
 
-// dx = a*dz + k1*x + k0 (+ add)
+// dx = a*dz + k1*x + k0 (+ add).  grid (slabs, n), the thread layout of the partial pass: a thread keeps ONE 8-channel
+// group of its image and walks the slab's pixels, so the four per-(image, channel) coefficient vectors are loaded once
+// per thread instead of once per 16 bytes of x (a flat grid-stride version issued 128 B of coefficient loads per 48 B of
+// tensor loads and streamed at 4.7 TB/s), and several pixels' loads are in flight per thread.
 __global__ void __launch_bounds__(256)
 gn_bwd_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const float* __restrict__ aa,
                     const float* __restrict__ ab, const float* __restrict__ k1, const float* __restrict__ k0,
-                    const uint16_t* __restrict__ add, uint16_t* __restrict__ out, int n, int h, int w, int c,
+                    const uint16_t* __restrict__ add, uint16_t* __restrict__ out, int h, int w, int c, int slabs,
                     int silu, int dy_mode, int add_mode) {
-  const int cg = c / 8;
-  const long long items = (long long)n * h * w * cg;
+  const int hw = h * w;
+  const int groups8 = c / 8;
+  const int lanes = blockDim.x / groups8;
+  const int lane = threadIdx.x / groups8, g8 = threadIdx.x % groups8;
+  if (lane >= lanes) return;
+  const int slab = blockIdx.x, img = blockIdx.y;
+  const int per = (hw + slabs - 1) / slabs;
+  const int p_begin = slab * per, p_end = min(hw, p_begin + per);
   const float dys = dy_mode ? 0.25f : 1.0f, adds = add_mode ? 0.25f : 1.0f;
-  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
-       it += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(it % cg);
-    const long long pix = it / cg;
-    const int px = (int)(pix % w), py = (int)((pix / w) % h), img = (int)(pix / ((long long)w * h));
-    const int ch = g * 8;
+  const int ch = g8 * 8;
+  const long long cb = (long long)img * c + ch;
+  float a8[8], b8[8], k18[8], k08[8];
+  *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(aa + cb);
+  *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(aa + cb + 4);
+  *reinterpret_cast<float4*>(k18) = *reinterpret_cast<const float4*>(k1 + cb);
+  *reinterpret_cast<float4*>(k18 + 4) = *reinterpret_cast<const float4*>(k1 + cb + 4);
+  *reinterpret_cast<float4*>(k08) = *reinterpret_cast<const float4*>(k0 + cb);
+  *reinterpret_cast<float4*>(k08 + 4) = *reinterpret_cast<const float4*>(k0 + cb + 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b8[j] = 0.0f;
+  if (silu) {
+    *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + cb);
+    *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + cb + 4);
+  }
+#pragma unroll 2
+  for (int p = p_begin + lane; p < p_end; p += lanes) {
+    const long long pix = (long long)img * hw + p;
+    const int py = p / w, px = p - py * w;
     const uint4 xv = *reinterpret_cast<const uint4*>(x + pix * c + ch);
     const uint4 gv = *reinterpret_cast<const uint4*>(dy + src_pixel(dy_mode, img, py, px, h, w) * c + ch);
     uint4 av = make_uint4(0, 0, 0, 0);
     if (add) av = *reinterpret_cast<const uint4*>(add + src_pixel(add_mode, img, py, px, h, w) * c + ch);
     const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w}, gu[4] = {gv.x, gv.y, gv.z, gv.w}, au[4] = {av.x, av.y, av.z, av.w};
-    float r[8], a8[8], b8[8], k18[8], k08[8];
-    const long long cb = (long long)img * c + ch;
-    *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(aa + cb);
-    *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(aa + cb + 4);
-    *reinterpret_cast<float4*>(k18) = *reinterpret_cast<const float4*>(k1 + cb);
-    *reinterpret_cast<float4*>(k18 + 4) = *reinterpret_cast<const float4*>(k1 + cb + 4);
-    *reinterpret_cast<float4*>(k08) = *reinterpret_cast<const float4*>(k0 + cb);
-    *reinterpret_cast<float4*>(k08 + 4) = *reinterpret_cast<const float4*>(k0 + cb + 4);
-    if (silu) {
-      *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + cb);
-      *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + cb + 4);
-    }
+    float r[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xx = (j & 1) ? adm_hi_f32(xu[j >> 1]) : adm_lo_f32(xu[j >> 1]);
@@ -423,11 +435,15 @@ extern "C" int adm_gn_bwd_apply(const adm_bf16* x, const adm_bf16* dy, const flo
                                 const float* k1, const float* k0, const adm_bf16* add, adm_bf16* out, int n, int h,
                                 int w, int c, int silu, int dy_half, int add_half, void* stream) {
   ADM_REQUIRE(x && dy && aff_a && aff_b && k1 && k0 && out, ADM_E_ARG, "adm_gn_bwd_apply: null pointer");
-  ADM_REQUIRE(n > 0 && h > 0 && w > 0 && c % 8 == 0, ADM_E_SHAPE, "adm_gn_bwd_apply: bad shape");
+  ADM_REQUIRE(n > 0 && h > 0 && w > 0 && c % 8 == 0 && c <= 2048, ADM_E_SHAPE, "adm_gn_bwd_apply: bad shape");
+  ADM_REQUIRE(!(dy_half || add_half) || (h % 2 == 0 && w % 2 == 0), ADM_E_SHAPE, "adm_gn_bwd_apply: odd size with a half-resolution operand");
   ADM_REQUIRE(adm_aligned16(x) && adm_aligned16(dy) && adm_aligned16(add) && adm_aligned16(out), ADM_E_ALIGN,
               "adm_gn_bwd_apply: unaligned pointer");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long long)n * h * w * (c / 8))), dim3(256), 0,
-                     (hipStream_t)stream, x, dy, aff_a, aff_b, k1, k0, add, out, n, h, w, c, silu, dy_half, add_half);
+  const int hw = h * w;
+  const int slabs = hw >= 64 ? hw / 64 : 1;   // 64 pixels per block (the pass is elementwise: any split gives the same bits)
+  ADM_REQUIRE(slabs <= 65535 && n <= 65535, ADM_E_SHAPE, "adm_gn_bwd_apply: grid too large");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(slabs, n), dim3(256), 0,
+                     (hipStream_t)stream, x, dy, aff_a, aff_b, k1, k0, add, out, h, w, c, slabs, silu, dy_half, add_half);
   return adm_check_launch("adm_gn_bwd_apply");
 }
 

@@ -268,7 +268,10 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
   ADM_REQUIRE((table == nullptr) == (idx == nullptr), ADM_E_ARG, "adm_linear_f32: table and idx go together");
   hipStream_t s = (hipStream_t)stream;
   const size_t small_lds = (size_t)LS_ROWS * k * sizeof(float);
-  if (n <= 64 && k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
+  const bool mfma_ok = k % 16 == 0 && adm_aligned16(w) && adm_aligned16(in);
+  // few rows: the GEMV-shaped kernel (below 32 rows a 64-row MFMA tile is mostly empty; at 64 rows x 1024 -> 40 960
+  // -- the LSUN-256 model's emb_layers at batch 64 -- it took 421 us against ~100 on the matrix pipe)
+  if (n <= 64 && !(mfma_ok && n >= 32) && k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
     static bool attr_set[64][2] = {};  // per device: opt in to the dynamic LDS size once per instantiation
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -285,7 +288,7 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
     else hipLaunchKernelGGL((linear_small_kernel<false>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
     return adm_check_launch("adm_linear_f32");
   }
-  if (k % 16 == 0 && adm_aligned16(w) && adm_aligned16(in)) {
+  if (mfma_ok) {
     dim3 g((o + 31) / 32, (n + 255) / 256);
     // 16 k-values per step: 32- and 64-deep steps (KU = 2, 4) measured 15 % slower (205 vs 179 us on 256 x 768 -> 33 792)
     if (silu_in) hipLaunchKernelGGL((linear_mfma_kernel<true, 1>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
