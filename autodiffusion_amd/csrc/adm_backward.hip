@@ -440,7 +440,7 @@ extern "C" int adm_gn_bwd_apply(const adm_bf16* x, const adm_bf16* dy, const flo
   ADM_REQUIRE(adm_aligned16(x) && adm_aligned16(dy) && adm_aligned16(add) && adm_aligned16(out), ADM_E_ALIGN,
               "adm_gn_bwd_apply: unaligned pointer");
   const int hw = h * w;
-  const int slabs = hw >= 64 ? hw / 64 : 1;   // 64 pixels per block (the pass is elementwise: any split gives the same bits)
+  const int slabs = hw >= 64 ? hw / 64 : 1;   // 64 pixels per block, measured against 128 / 256 (the pass is elementwise: any split gives the same bits)
   ADM_REQUIRE(slabs <= 65535 && n <= 65535, ADM_E_SHAPE, "adm_gn_bwd_apply: grid too large");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(slabs, n), dim3(256), 0,
                      (hipStream_t)stream, x, dy, aff_a, aff_b, k1, k0, add, out, h, w, c, slabs, silu, dy_half, add_half);
