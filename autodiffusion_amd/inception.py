@@ -76,7 +76,7 @@ class InceptionV3:
 
     DEFAULT_BLOCK_INDEX = 3
     BLOCK_INDEX_BY_DIM = {64: 0, 192: 1, 768: 2, 2048: 3}
-    CHUNK = 100   # images per pass: bounds the transient activations (~16 MB per image) and the 2 GiB buffer-offset range
+    CHUNK = 320   # images per pass: the 8x8 and 17x17 levels need this many to fill 256 CUs (100: -16 %); bounded by the 2 GiB buffer-offset range of the 299x299x32 input (375 images) and ~16 MB of transient activations per image
 
     def __init__(self, output_blocks: Sequence[int] = (DEFAULT_BLOCK_INDEX,), resize_input: bool = True,
                  normalize_input: bool = True, requires_grad: bool = False, use_fid_inception: bool = True,

@@ -36,10 +36,11 @@ def main():
     for dt in (torch.float16, torch.bfloat16):
         m = InceptionV3(dtype=dt).to(DEV)
         m.weights_loaded = True   # random weights on purpose: a throughput run
-        for size, n in ((64, 100), (256, 100), (64, 500)):
+        for size, n, chunk in ((64, 100, 100), (256, 100, 100), (64, 256, 256), (64, 640, 100), (64, 640, 200), (64, 640, 320)):
+            m.CHUNK = chunk
             u8 = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device=DEV)
             ms = timeit(lambda: m.features(u8), reps=5)
-            print(f"{str(dt):16s} {n:4d} x {size}x{size} uint8 -> pool3: {ms:8.2f} ms  {n / ms * 1e3:8.0f} images/s  "
+            print(f"{str(dt):16s} {n:4d} x {size}x{size} uint8 (passes of {chunk}) -> pool3: {ms:8.2f} ms  {n / ms * 1e3:8.0f} images/s  "
                   f"{GFLOP_PER_IMAGE * n / ms:7.1f} TFLOP/s")
     # single layers at batch 100 (fp16)
     n = 100
