@@ -20,6 +20,8 @@
 // pixel: bias + ReLU + one 8-byte store per accumulator, no transposition.  This kernel trades the LDS-staged tile
 // machinery of adm_conv (fused GroupNorm prologue, persistent tiles) for generality (any kernel size / stride / padding /
 // channel slice); it is sized for the ~11 GFLOP/image Inception network, 1 % of a candidate's sampling FLOPs.
+#include <stdlib.h>
+
 #include "adm_common.h"
 
 namespace {
@@ -134,6 +136,156 @@ convg_kernel(const ConvG p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long long m = m0 + i * 16 + lc;
+      if (m >= p.M) continue;
+      float v0 = acc[j][i][0] + b.x, v1 = acc[j][i][1] + b.y, v2 = acc[j][i][2] + b.z, v3 = acc[j][i][3] + b.w;
+      if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      uint2 o;
+      o.x = adm_pack2(v0, v1);
+      o.y = adm_pack2(v2, v3);
+      *reinterpret_cast<uint2*>(p.out + m * p.out_stride + co) = o;
+    }
+  }
+}
+
+// The same implicit GEMM with both operand tiles staged through LDS (layers with >= 33 output channels).  In the LDS-free
+// kernel above every wave fetches its own 64-pixel and 64-channel fragments: 8 KB through the L1 per 16 MFMAs, 32 FLOP per
+// byte against the 64 the CU's 64 B/clk load path needs to keep the matrix pipe busy -- measured 130-320 TFLOP/s.  Here a
+// block of 4 waves (WM x WN, each 64 pixels x 64 channels) shares one K-step of both operands: (WM + WN) * 4 KB per step go
+// global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip; out-of-image taps, pixels past the tensor and
+// channels past cout arrive as zeros), double-buffered, one barrier per step, and each wave reads its 4 + 4 fragments with
+// ds_read_b128.  A DMA piece is lane-linear (1 KB = 16 rows of 64 B), so the rows are unpadded and the 16-byte slot of
+// k-quarter q in row r is q ^ ((r >> 1) & 3): applied on the global side of the DMA and on every fragment read;
+// conflict-free for the four 16-lane groups of ds_read_b128 (checked exhaustively).
+template <int WM, int WN>
+__global__ void __launch_bounds__(256)
+convg_lds_kernel(const ConvG p) {
+  constexpr int TM = 4, TN = 4, BM = WM * 64, BN = WN * 64;
+  constexpr int NA = BM / 16, NB = BN / 16, NP = NA + NB, NPW = NP / 4;   // 1 KB DMA pieces per K-step: pixels, channels, per wave
+  static_assert(WM * WN == 4 && NP % 4 == 0, "4 waves");
+  constexpr int STAGE = NP * 1024, NS = 3;   // ring of 3 stages: the DMA of step s + 2 flies during step s (one step of
+  __shared__ __attribute__((aligned(1024))) unsigned char tiles[NS * STAGE];   // 16 MFMAs is far shorter than a global round trip)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lc = lane & 15, lq = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int co0 = blockIdx.y * BN;
+  const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  const int taps = p.KH * p.KW, chunks = p.cin_pad >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)tiles;
+
+  // ---- the DMA pieces of this wave: piece q = wave + 4 * u; pieces [0, NA) are pixel rows, [NA, NP) channel rows.
+  // lane -> row (lane >> 2) of the piece, LDS slot lane & 3, i.e. global k-quarter (lane & 3) ^ ((row >> 1) & 3)
+  const unsigned gq16 = (unsigned)((lane & 3) ^ ((lane >> 3) & 3)) * 16u;
+  int pbase[NPW], iy0[NPW], ix0[NPW];
+  unsigned wrow[NPW];
+#pragma unroll
+  for (int u = 0; u < NPW; ++u) {
+    const int q = wave + 4 * u;
+    pbase[u] = 0; iy0[u] = -(1 << 20); ix0[u] = 0; wrow[u] = CG_OOB;
+    if (q < NA) {
+      const long long m = m0 + q * 16 + (lane >> 2);
+      if (m < p.M) {
+        const int ox = (int)(m % p.OW);
+        const long long t = m / p.OW;
+        const int oy = (int)(t % p.OH), img = (int)(t / p.OH);
+        pbase[u] = img * p.H * p.W;
+        iy0[u] = oy * p.stride - p.pad_h;
+        ix0[u] = ox * p.stride - p.pad_w;
+      }
+    } else {
+      const int co = co0 + (q - NA) * 16 + (lane >> 2);
+      if (co < p.cout) wrow[u] = (unsigned)co * (unsigned)(taps * p.cin_pad * 2) + gq16;
+    }
+  }
+  unsigned aoff[NPW];
+  auto tap_offsets = [&](int ky, int kx) {
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      const int iy = iy0[u] + ky, ix = ix0[u] + kx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      aoff[u] = ok ? (unsigned)(pbase[u] + iy * p.W + ix) * (unsigned)(p.in_stride * 2) + gq16 : CG_OOB;
+    }
+  };
+  auto dma_step = [&](int buf, int tap, int c) {
+    const unsigned cb = (unsigned)c * 64u, wb = (unsigned)(tap * p.cin_pad) * 2u + cb;
+#pragma unroll
+    for (int u = 0; u < NPW; ++u) {
+      const int q = wave + 4 * u;                                  // wave-uniform
+      const unsigned dst = lds0 + (unsigned)buf * STAGE + (unsigned)q * 1024u;
+      unsigned keep;
+      if (q < NA) {
+        const unsigned v = aoff[u] == CG_OOB ? CG_OOB : aoff[u] + cb;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(v), "s"(rsi), "s"(dst) : "memory");
+      } else {
+        const unsigned v = wrow[u] == CG_OOB ? CG_OOB : wrow[u] + wb;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(v), "s"(rsw), "s"(dst) : "memory");
+      }
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row (16-row tile base + lc), slot lq ^ ((lc >> 1) & 3)
+  const unsigned frag = (unsigned)lc * 64u + (unsigned)(lq ^ ((lc >> 1) & 3)) * 16u;
+  const unsigned xfrag = (unsigned)(wm * 4) * 1024u + frag, wfrag = (unsigned)(NA + wn * 4) * 1024u + frag;
+
+  int ky = 0, kx = 0, tap = 0, c = 0;   // (tap, chunk) of the step whose DMA is issued next
+  const int steps = taps * chunks;
+  auto advance = [&]() {
+    if (++c == chunks) {
+      c = 0;
+      ++tap;
+      if (++kx == p.KW) { kx = 0; ++ky; }
+      tap_offsets(ky, kx);
+    }
+  };
+  tap_offsets(0, 0);
+  dma_step(0, 0, 0);
+  if (steps > 1) { advance(); dma_step(1, tap, c); }
+  if (steps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");   // step 0 has landed, step 1 may still fly
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int stage = 0;
+  for (int s = 0; s < steps; ++s) {
+    const bool more = s + 2 < steps;
+    if (more) {
+      advance();
+      dma_step(stage >= 1 ? stage - 1 : NS - 1, tap, c);   // stage (s + 2) % 3, last read in step s - 1
+    }
+    const unsigned char* st = tiles + stage * STAGE;
+    adm_h8 xa[TM], wa[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const adm_h8*>(st + xfrag + i * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wa[j] = *reinterpret_cast<const adm_h8*>(st + wfrag + j * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[j][i] = adm_mfma_16x16x32(wa[j], xa[i], acc[j][i], 0, 0, 0);
+    // this wave's pieces of step s + 1 have landed (those of step s + 2, issued above, may still fly)
+    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // ... everyone's have, and everyone is done reading this stage
+    stage = stage == NS - 1 ? 0 : stage + 1;
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = co0 + wn * 64 + j * 16 + 4 * lq;
+    if (co + 3 >= p.cout) continue;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long m = m0 + wm * 64 + i * 16 + lc;
       if (m >= p.M) continue;
       float v0 = acc[j][i][0] + b.x, v1 = acc[j][i][1] + b.y, v2 = acc[j][i][2] + b.z, v3 = acc[j][i][3] + b.w;
       if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
@@ -295,13 +447,18 @@ extern "C" int adm_conv2d(const adm_conv2d_args* a, void* stream) {
   k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
   k.M = (long long)a->n * oh * ow;
   const long long mblocks = (k.M + 255) / 256;
-  ADM_REQUIRE(mblocks < (1ll << 31), ADM_E_SHAPE, "adm_conv2d: too many pixels");
-  // Cout block width: the one that pads cout least (ties: the wider)
-  const int pad64 = (a->cout + 63) / 64 * 64, pad32 = (a->cout + 31) / 32 * 32;
+  ADM_REQUIRE(mblocks < (1ll << 30), ADM_E_SHAPE, "adm_conv2d: too many pixels");
   hipStream_t s = (hipStream_t)stream;
-  // (a 128-wide wave tile -- 12 fragment loads per 32 MFMAs instead of 8 per 16 -- measured +7 % on 288 -> 384 @ 35x35 and
-  // -35 % on the 8x8 level, where it halves an already short grid: not built)
-  if (pad32 < pad64) hipLaunchKernelGGL((convg_kernel<2>), dim3((unsigned)mblocks, pad32 / 32), dim3(256), 0, s, k);
+  // Cout block width by least padding: 128 (LDS kernel, 128 pixels x 128 channels) where rounding cout up to 128 costs no more
+  // than rounding to 64, else 64 (LDS kernel, 256 x 64); 32 output channels or fewer: the LDS-free kernel, 256 x 32.
+  // (A 128-wide wave tile in the LDS-free kernel -- 12 fragment loads per 32 MFMAs instead of 8 per 16 -- measured +7 % on
+  // 288 -> 384 @ 35x35 and -35 % on the 8x8 level, where it halves an already short grid: not built.)
+  static const bool no_lds = getenv("ADM_CG_NO_LDS") != nullptr;   // A/B switch for measurements
+  const int pad128 = (a->cout + 127) / 128 * 128, pad64 = (a->cout + 63) / 64 * 64, pad32 = (a->cout + 31) / 32 * 32;
+  if (a->cout > 32 && !no_lds) {
+    if (pad128 == pad64) hipLaunchKernelGGL((convg_lds_kernel<2, 2>), dim3((unsigned)((k.M + 127) / 128), pad128 / 128), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((convg_lds_kernel<4, 1>), dim3((unsigned)mblocks, pad64 / 64), dim3(256), 0, s, k);
+  } else if (pad32 < pad64) hipLaunchKernelGGL((convg_kernel<2>), dim3((unsigned)mblocks, pad32 / 32), dim3(256), 0, s, k);
   else hipLaunchKernelGGL((convg_kernel<4>), dim3((unsigned)mblocks, pad64 / 64), dim3(256), 0, s, k);
   return adm_check_launch("adm_conv2d");
 }
