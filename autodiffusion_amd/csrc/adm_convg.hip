@@ -10,16 +10,17 @@
 // BatchNorm into the packed weights (scale) and a bias (adm_pack_conv2d_weight), every branch writes its channel slice
 // of the block's concatenated NHWC output directly (out_stride), so a block is conv launches + one or two pool launches.
 //
-// adm_conv2d is an implicit GEMM, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel] with k = (tap, channel): a wave owns
-// TN*16 output channels x 64 output pixels, a block 4 waves = 256 pixels of one Cout block.  Both operands are
-// K-contiguous in memory (NHWC activations with the channel count padded to 32, weights packed [cout][tap][cin_pad]),
-// so a lane's MFMA fragment -- 8 consecutive channels of one pixel / one output channel at one tap -- is ONE 16-byte
-// buffer load straight from global memory: no LDS, no barrier, out-of-image taps and rows beyond the tensor read as
-// hardware zeros through the buffer descriptor (offset bit 31).  The next K-step's fragments are in flight during the
-// current step's MFMAs.  The weights are the A operand, so a lane ends up with 4 CONSECUTIVE output channels of one
-// pixel: bias + ReLU + one 8-byte store per accumulator, no transposition.  This kernel trades the LDS-staged tile
-// machinery of adm_conv (fused GroupNorm prologue, persistent tiles) for generality (any kernel size / stride / padding /
-// channel slice); it is sized for the ~11 GFLOP/image Inception network, 1 % of a candidate's sampling FLOPs.
+// adm_conv2d is an implicit GEMM, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel] with k = (tap, channel).  Both operands are
+// K-contiguous in memory (NHWC activations with the channel count padded to 32, weights packed [cout][tap][cin_pad]), so a
+// lane's MFMA fragment -- 8 consecutive channels of one pixel / one output channel at one tap -- is 16 contiguous bytes;
+// out-of-image taps, pixels beyond the tensor and channels beyond cout read as hardware zeros through the buffer descriptor
+// (offset bit 31).  The weights are the A operand, so a lane ends up with 4 CONSECUTIVE output channels of one pixel:
+// bias + ReLU + one 8-byte store per accumulator, no transposition.  Two kernels:
+//   * convg_lds_kernel (layers with more than 32 output channels): a block's K-step of both operands goes global -> LDS by
+//     LDS-DMA into a 3-stage ring of XOR-swizzled 64-byte rows, one barrier per step; 230-640 TFLOP/s per layer
+//   * convg_kernel (32 output channels or fewer: the first two layers): LDS-free, every wave fetches its own fragments
+// These trade the LDS-staged halo tiles of adm_conv (fused GroupNorm prologue, persistent tiles, 1000+ TFLOP/s) for
+// generality (any kernel size / stride / padding / channel slice); sized for the ~11 GFLOP/image Inception network.
 #include <stdlib.h>
 
 #include "adm_common.h"
