@@ -57,25 +57,38 @@ def test_search_cli_one_rank_vs_image_sharded_vs_population_parallel(tmp_path):
     assert log2.count("epoch = 0 : top") == 1
 
 
-def test_search_cli_with_the_bundled_inception_extractor(tmp_path):
-    """No --features: the HIP Inception-v3 pool3 extractor scores the candidates (random weights here -- the checkpoint
-    is not in the image -- so the FID values mean nothing; the path from uint8 batches to the "top" report is what runs)."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    ref = str(tmp_path / "ref.npz")
-    rng = np.random.RandomState(0)
-    a = rng.randn(2048, 2048) / 45.0
-    np.savez(ref, mu=rng.randn(2048) * 0.1, sigma=a @ a.T + 0.1 * np.eye(2048))
+def _run_bundled(tmp_path, tag, nproc):
+    ref = str(tmp_path / "ref2048.npz")
+    if not os.path.exists(ref):
+        rng = np.random.RandomState(0)
+        a = rng.randn(2048, 2048) / 45.0
+        np.savez(ref, mu=rng.randn(2048) * 0.1, sigma=a @ a.T + 0.1 * np.eye(2048))
     flags = [f for f in FLAGS]
     i = flags.index("--features")
     del flags[i:i + 2]
-    save = str(tmp_path / "inc")
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "search_ea.py")] + flags + ["--save_dir", save, "--ref_path", ref,
-                                                                                      "--fid_on_device", "True", "--max_epochs", "1"]
-    env = dict(os.environ, OMP_NUM_THREADS="4", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    save = str(tmp_path / tag)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "scripts", "search_ea.py")] + flags + [
+               "--save_dir", save, "--ref_path", ref, "--fid_on_device", "True", "--max_epochs", "1"]
+    env = dict(os.environ, ADM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "RANDOM weights" in r.stderr
     log = open(os.path.join(save, "log.txt")).read()
     top = re.findall(r"^No\.(\d+) (\[.*?\]) fid = ([-0-9.e+]+)$", log, flags=re.M)
     assert top and all(np.isfinite(float(f)) for _, _, f in top), log[-2000:]
+    return [(c, float(f)) for _, c, f in top]
+
+
+def test_search_cli_with_the_bundled_inception_extractor(tmp_path):
+    """No --features: the HIP Inception-v3 pool3 extractor scores the candidates (random weights here -- the checkpoint
+    is not in the image -- so the FID values mean nothing; the path from uint8 batches to the "top" report is what runs),
+    on one rank and with every candidate's images sharded over two ranks (features are per image, the float64 sums pooled)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    top1 = _run_bundled(tmp_path, "inc1", 1)
+    top2 = _run_bundled(tmp_path, "inc2", 2)
+    assert [c for c, _ in top1] == [c for c, _ in top2]
+    np.testing.assert_allclose([f for _, f in top2], [f for _, f in top1], rtol=1e-6, atol=1e-6)
