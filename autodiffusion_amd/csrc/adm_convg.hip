@@ -381,37 +381,41 @@ global_avgpool_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, 
 __global__ void __launch_bounds__(256)
 resize_bilinear_kernel(const void* __restrict__ in, uint16_t* __restrict__ out, int n, int h, int w, int oh, int ow,
                        int cpad, int kind, int half_pixel, float scale, float shift) {
-  const long long items = (long long)n * oh * ow;
+  // one thread per 16-byte segment of an output pixel (consecutive lanes write consecutive segments: a pixel-per-thread
+  // version wrote its 64 bytes as four 16-byte stores 64 bytes apart and ran at 1.5 TB/s); segment 0 holds the image
+  const int segs = cpad / 8;
+  const long long items = (long long)n * oh * ow * segs;
   const float ry = (float)h / (float)oh, rx = (float)w / (float)ow;
   for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
-    const int ox = (int)(it % ow), oy = (int)((it / ow) % oh), img = (int)(it / ((long long)ow * oh));
-    float sy = half_pixel ? ((float)oy + 0.5f) * ry - 0.5f : (float)oy * ry;
-    float sx = half_pixel ? ((float)ox + 0.5f) * rx - 0.5f : (float)ox * rx;
-    sy = fmaxf(sy, 0.0f);
-    sx = fmaxf(sx, 0.0f);
-    const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
-    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-    const float fy = sy - (float)y0, fx = sx - (float)x0;
-    float v[3];
+    const int sg = (int)(it % segs);
+    const long long pix = it / segs;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (sg == 0) {
+      const int ox = (int)(pix % ow), oy = (int)((pix / ow) % oh), img = (int)(pix / ((long long)ow * oh));
+      float sy = half_pixel ? ((float)oy + 0.5f) * ry - 0.5f : (float)oy * ry;
+      float sx = half_pixel ? ((float)ox + 0.5f) * rx - 0.5f : (float)ox * rx;
+      sy = fmaxf(sy, 0.0f);
+      sx = fmaxf(sx, 0.0f);
+      const int y0 = min((int)sy, h - 1), x0 = min((int)sx, w - 1);
+      const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+      const float fy = sy - (float)y0, fx = sx - (float)x0;
+      float v[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      auto at = [&](int y, int x) -> float {
-        if (kind == 0) return (float)reinterpret_cast<const uint8_t*>(in)[(((long long)img * h + y) * w + x) * 3 + ch];
-        if (kind == 1) return reinterpret_cast<const float*>(in)[(((long long)img * 3 + ch) * h + y) * w + x];
-        return reinterpret_cast<const float*>(in)[(((long long)img * h + y) * w + x) * 3 + ch];
-      };
-      // the operation order of both references: interpolate along x on the two rows, then along y
-      const float top = at(y0, x0) * (1.0f - fx) + at(y0, x1) * fx;
-      const float bot = at(y1, x0) * (1.0f - fx) + at(y1, x1) * fx;
-      v[ch] = (top * (1.0f - fy) + bot * fy) * scale + shift;
+      for (int ch = 0; ch < 3; ++ch) {
+        auto at = [&](int y, int x) -> float {
+          if (kind == 0) return (float)reinterpret_cast<const uint8_t*>(in)[(((long long)img * h + y) * w + x) * 3 + ch];
+          if (kind == 1) return reinterpret_cast<const float*>(in)[(((long long)img * 3 + ch) * h + y) * w + x];
+          return reinterpret_cast<const float*>(in)[(((long long)img * h + y) * w + x) * 3 + ch];
+        };
+        // the operation order of both references: interpolate along x on the two rows, then along y
+        const float top = at(y0, x0) * (1.0f - fx) + at(y0, x1) * fx;
+        const float bot = at(y1, x0) * (1.0f - fx) + at(y1, x1) * fx;
+        v[ch] = (top * (1.0f - fy) + bot * fy) * scale + shift;
+      }
+      val.x = adm_pack2(v[0], v[1]);
+      val.y = adm_pack2(v[2], 0.0f);
     }
-    uint16_t* o = out + it * cpad;
-    uint4 first;
-    first.x = adm_pack2(v[0], v[1]);
-    first.y = adm_pack2(v[2], 0.0f);
-    first.z = 0; first.w = 0;
-    *reinterpret_cast<uint4*>(o) = first;
-    for (int c8 = 8; c8 < cpad; c8 += 8) *reinterpret_cast<uint4*>(o + c8) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(out + it * 8) = val;
   }
 }
 
@@ -507,7 +511,7 @@ extern "C" int adm_resize_bilinear(const void* in, adm_bf16* out, int n, int h, 
   ADM_REQUIRE(n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && cpad >= 8 && cpad % 8 == 0 && kind >= 0 && kind <= 2, ADM_E_ARG,
               "adm_resize_bilinear: bad arguments");
   ADM_REQUIRE(adm_aligned16(out), ADM_E_ALIGN, "adm_resize_bilinear: unaligned output");
-  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for_items((long long)n * oh * ow)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for_items((long long)n * oh * ow * (cpad / 8))), dim3(256), 0, (hipStream_t)stream,
                      in, reinterpret_cast<uint16_t*>(out), n, h, w, oh, ow, cpad, kind, half_pixel, scale, shift);
   return adm_check_launch("adm_resize_bilinear");
 }
