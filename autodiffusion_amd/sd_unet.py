@@ -10,7 +10,7 @@ Engine: activations are bf16 NHWC, so a token of the SpatialTransformer IS a pix
 1x1 launch.  Per block:
   ResBlock (openaimodel.py:236-262)   gn -> conv3x3[affine+SiLU] -> gn of (h + emb) folded into the affine
                                       (adm_gn_finalize_add: h + emb is never written) -> conv3x3[affine+SiLU, +skip]
-  Downsample (:118-145)               stride-1 conv3x3 + every-second-pixel pick (first build: 4x the MACs of 3 layers)
+  Downsample (:118-145)               stride-2 conv3x3 at its 9 taps per output pixel (adm_conv2d); ADM_SD_STRIDE2=0: stride-1 conv + pick
   Upsample (:78-104)                  conv3x3 reading its input through the virtual nearest 2x upsample (in_up)
   SpatialTransformer (attention.py:218-260)
       gn(eps 1e-6) -> 1x1 proj_in [affine prologue]
@@ -23,6 +23,7 @@ Engine: activations are bf16 NHWC, so a token of the SpatialTransformer IS a pix
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List
 
 import torch
@@ -34,6 +35,9 @@ from .sd_arch import (SDDownSpec, SDResBlockSpec, SDStemSpec, SDTransformerSpec,
 from .unet import HipModule, _Prep
 
 _HEAD_WIDTHS = (32, 48, 64, 80, 96, 128, 160, 192, 256)
+# Downsample (openaimodel.py:149-152): the stride-2 3x3 conv at its own 9 taps per OUTPUT pixel (adm_conv2d), or as a stride-1
+# conv on the faster tile kernel + an every-second-pixel pick (4 x the MACs); A/B switch ADM_SD_STRIDE2
+STRIDE2_TAPS = os.environ.get("ADM_SD_STRIDE2", "1") != "0"
 
 
 def _padded_head(d: int) -> int:
@@ -124,7 +128,8 @@ class UNetModel(HipModule):
                     d["wsb"] = f32(f"{p}.skip_connection.bias")
                 pr.blocks[p] = d
             elif isinstance(b, SDDownSpec):
-                pr.blocks[p] = dict(w=pack(P[f"{p}.op.weight"]), b=f32(f"{p}.op.bias"))
+                pr.blocks[p] = dict(w=pack(P[f"{p}.op.weight"]), b=f32(f"{p}.op.bias"),
+                                    w2d=ops.pack_conv2d_weight(P[f"{p}.op.weight"], None, self.compute_dtype))   # real stride-2 taps (adm_conv2d)
             elif isinstance(b, SDUpSpec):
                 pr.blocks[p] = dict(w=pack(P[f"{p}.conv.weight"]), b=f32(f"{p}.conv.bias"))
             elif isinstance(b, SDTransformerSpec):
@@ -217,7 +222,10 @@ class UNetModel(HipModule):
             elif isinstance(blk, SDTransformerSpec):
                 h = self._transformer(pr, blk, h, kvs, n_ctx)
             elif isinstance(blk, SDDownSpec):
-                h = ops.resample(ops.conv(h, d["w"], d["b"], blk.channels, 9), "stride2")
+                if STRIDE2_TAPS:   # the 9 taps at the output pixels only (general conv2d kernel, csrc/adm_convg.hip)
+                    h = ops.conv2d(h, d["w2d"], d["b"], 3, 3, stride=2, pad=(1, 1), relu=False)
+                else:              # stride-1 conv + every-second-pixel pick: 4 x the MACs on the faster tile kernel
+                    h = ops.resample(ops.conv(h, d["w"], d["b"], blk.channels, 9), "stride2")
             elif isinstance(blk, SDUpSpec):
                 h = ops.conv(h, d["w"], d["b"], blk.channels, 9, in_up=True, want_stats=True)
             else:
