@@ -42,3 +42,25 @@ def test_argument_errors_surface_as_exceptions_without_a_gpu():
     assert lib.adm_pack_u8_nhwc(None, None, 1, 3, 8, 8, None) == -1
     co = _lib.StepCoefs()
     assert lib.adm_ddim_step(None, None, None, None, None, None, None, 1, 3, 8, 8, C.byref(co), None) == -1
+
+
+def test_header_is_plain_c_and_links_from_a_c_client(tmp_path):
+    """include/adm_hip.h compiles as C99 (-pedantic: no C++isms, no torch types) and a C program links against the library."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "client.c"
+    src.write_text('#include "adm_hip.h"\n'
+                   "int main(void) {\n"
+                   "  adm_conv_args a; adm_conv2d_args b; adm_step_coefs c; (void)a; (void)b; (void)c;\n"
+                   "  if (adm_conv(0, 0) != ADM_E_ARG) return 2;            /* argument errors need no GPU */\n"
+                   "  if (!adm_last_error() || !adm_last_error()[0]) return 3;\n"
+                   "  return adm_abi_version() == ADM_ABI_VERSION ? 0 : 1;\n"
+                   "}\n")
+    libdir = os.path.join(ROOT, "autodiffusion_amd")
+    exe = str(tmp_path / "client")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                        "-L", libdir, "-l:libadm_hip.so", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([exe]).returncode == 0
