@@ -297,10 +297,10 @@ class InceptionV3:
         self._prepare()
         if u8_nhwc.dtype != torch.uint8 or u8_nhwc.dim() != 4 or u8_nhwc.shape[3] != 3:
             raise AdmError(f"InceptionV3.features: expected uint8 [N, H, W, 3], got {u8_nhwc.dtype} {tuple(u8_nhwc.shape)}")
+        if mode not in ("tf1", "pt"):
+            raise ValueError(f"mode must be 'tf1' or 'pt', got {mode!r}")
         u8_nhwc = u8_nhwc.to(self.device).contiguous()
         half, scale, shift = (False, 1.0 / 128.0, -1.0) if mode == "tf1" else (True, 2.0 / 255.0, -1.0)
-        if mode not in ("tf1", "pt"):
-            raise ValueError(mode)
         outs = []
         for i in range(0, u8_nhwc.shape[0], self.CHUNK):
             x = ops.resize_bilinear(u8_nhwc[i:i + self.CHUNK], 299, 299, 32, "u8_nhwc", half, scale, shift, self.compute_dtype)
