@@ -35,3 +35,21 @@ def test_bench_two_ranks_prints_one_consistent_json_line(workload):
     assert out["dtype"] == "bf16" and "synthetic" in out["data"] and out["value"] > 0
     # value = units all ranks processed / the (max-over-ranks) time of the K timed steps
     assert abs(out["value"] - 2 * batch / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]
+
+
+def test_bench_single_rank_line_with_the_fid_stage_and_roofline():
+    """The N = 1 line as the driver reads it, at a small batch: roofline object from live HIP events, and --with-fid puts the
+    Inception + Gram stage inside the step (config.fid_stage_in_step)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+           "--with-fid"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["fid_stage_in_step"] is True and out["unit"] == "images/sec"
+    roof = out["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["launches"] > 0
