@@ -14,10 +14,10 @@ Mirrors reference evaluations/evaluator_v1.py: ``FIDStatistics`` (:109-157),
   evaluates the same quantity on the GPU from the pooled device sums: tr sqrtm(S1 S2) = sum sqrt(eig(S1^1/2 S2 S1^1/2)),
   two symmetric float64 eigendecompositions (rocSOLVER through ``torch.linalg.eigh``: a plain library factorisation).
 
-The Inception-v3 pool3 extractor itself (a frozen TensorFlow graph fetched from a URL,
-evaluator_v1.py:652-679) is third-party and not available offline; any callable
-``features(uint8 NHWC device batch) -> fp32 [B, D] device tensor`` (or the reference's own
-``Evaluator_v1``) plugs in.  "Parity unpinned" for the features themselves.
+The Inception-v3 pool3 extractor (in the reference a frozen TensorFlow graph fetched from a URL, evaluator_v1.py:652-679, or
+``pytorch_fid``) is ``autodiffusion_amd.inception.InceptionV3`` on HIP layers; its weights are not available offline, so the
+features' parity with the reference's is unpinned.  Any callable
+``features(uint8 NHWC device batch) -> fp32 [B, D] device tensor`` (or an ``Evaluator_v1``-style object) plugs in.
 """
 from __future__ import annotations
 

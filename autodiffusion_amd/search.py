@@ -13,8 +13,9 @@ What changes underneath:
     candidate (fid.ActivationAccumulator) instead of all-gathering every uint8 batch;
   * every batch is seeded by (seed, candidate, batch index, rank), so a candidate's FID does not depend
     on how the work was sharded;
-  * the Inception feature extractor is a plug-in: ``features(uint8 NHWC device batch) -> [B, D]``
-    or the reference's own ``Evaluator_v1`` object (then the reference's host cal_fid path is used).
+  * the Inception feature extractor is a plug: ``features(uint8 NHWC device batch) -> [B, D]`` -- the bundled HIP
+    Inception-v3 pool3 (``inception.InceptionV3(...).features``, parity unpinned: DESIGN.md section 9) or any other callable --
+    or an ``Evaluator_v1``-style object (then the reference's host cal_fid path is used).
 """
 from __future__ import annotations
 
