@@ -21,6 +21,7 @@ features' parity with the reference's is unpinned.  Any ca
 """
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Optional
 
@@ -88,9 +89,38 @@ class ActivationAccumulator:
         self.n = 0
         self.s1 = torch.zeros(dim, dtype=torch.float64, device=self.device)
         self.s2 = torch.zeros(dim, dim, dtype=torch.float64, device=self.device)
+        self._side = None       # stream of add_from()
+        self._pending = False
 
-    def add(self, acts: torch.Tensor, limit: Optional[int] = None):
+    OVERLAP = os.environ.get("ADM_FID_OVERLAP", "1") != "0"
+
+    def add_from(self, features, u8: torch.Tensor):
+        """add(features(u8)) on a SIDE stream, behind everything queued so far on the current stream: the extractor's launches
+        (small grids on the 8x8 / 17x17 levels at sampling batch sizes) then fill CUs next to the next batch's sampling
+        kernels instead of running between two batches.  Same launches in the same order on one stream: bitwise the sums of
+        add(); every reader of the sums joins first."""
+        if not (self.OVERLAP and u8.is_cuda):
+            self.add(features(u8))
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        u8.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            self.add(features(u8), _joined=True)
+        self._pending = True
+
+    def join(self):
+        """The current stream waits for the side stream's queued feature / accumulation work."""
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._pending = False
+
+    def add(self, acts: torch.Tensor, limit: Optional[int] = None, _joined: bool = False):
         """acts fp32 [B, dim]; `limit` keeps only the first rows (the reference's arr[:num_samples])."""
+        if not _joined:
+            self.join()
         if limit is not None:
             acts = acts[:limit]
         if acts.shape[0] == 0:
@@ -109,6 +139,7 @@ class ActivationAccumulator:
         [n | s1 (dim) | s2 (dim^2)] (8 B + 16 KiB + 32 MiB per rank at dim 2048), summed in rank order (deterministic).
         n rides in the buffer (exact in float64), so no per-rank host synchronisation is needed."""
         import torch.distributed as dist
+        self.join()
         if local or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return self.n, self.s1, self.s2
         world = dist.get_world_size(group)

@@ -120,7 +120,7 @@ class EvolutionSearcher(object):
             keep = max(0, min(args.batch_size, args.num_samples - start))
             if acc is not None:
                 if keep > 0:
-                    acc.add(self.features(u8[:keep]))
+                    acc.add_from(self.features, u8[:keep])   # on a side stream, next to the next batch's sampling
             else:
                 host_images.append(u8[:keep].cpu().numpy())
             produced += args.batch_size * world

@@ -340,7 +340,7 @@ def main():
         # deterministic, layout-independent seeding per (step, rank)
         u8 = ev.sample_batch(B, seed=(1000003 * step_idx + rank))
         if fid_net is not None:
-            fid_acc.add(fid_net.features(u8))
+            fid_acc.add_from(fid_net.features, u8)
         return u8
 
     for w in range(args.warmup):

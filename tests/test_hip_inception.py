@@ -210,3 +210,22 @@ def test_sd_driver_fid_helpers_parity_unpinned(nets):
         got = fid.calculate_fid(x, rmu, rsig, 4, DEV, dims, model=m)
         want = ofid.frechet_distance(*ofid.statistics(acts), rmu, rsig)
         assert abs(got - want) <= 1e-8 * max(1.0, abs(want))
+
+
+def test_overlapped_feature_accumulation_is_bitwise_the_sequential_one(nets):
+    """ActivationAccumulator.add_from runs extractor + Gram on a side stream next to the caller's stream: the same launches in
+    the same order, so the float64 sums are bitwise those of add(features(u8))."""
+    oi, p, InceptionV3 = nets
+    from autodiffusion_amd.fid import ActivationAccumulator
+    m = InceptionV3().to(DEV)
+    m.load_state_dict(p)
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.randint(0, 256, (6, 32, 32, 3), generator=g, dtype=torch.uint8).to(DEV) for _ in range(3)]
+    a, b = ActivationAccumulator(2048, DEV), ActivationAccumulator(2048, DEV)
+    for u8 in batches:
+        a.add(m.features(u8))
+        b.add_from(m.features, u8)
+        torch.randn(256, 256, device=DEV) @ torch.randn(256, 256, device=DEV)   # unrelated work on the caller's stream
+    na, s1a, s2a = a.pooled()
+    nb, s1b, s2b = b.pooled()
+    assert na == nb == 18 and torch.equal(s1a, s1b) and torch.equal(s2a, s2b)
