@@ -74,6 +74,12 @@ struct ConvK {
   // order together with bias and residual, rounds to bf16 and accumulates the output statistics
   int ksplit, cps;
   float* ws;
+  // up-conv phase launch (TAPS = 4 instantiations; adm_conv_args.up_phase): the conv3x3 of a nearest-neighbour 2x upsample,
+  // for the output pixels of ONE phase (2y + py, 2x + px), is a 2x2-tap conv of the half-resolution source with pre-summed
+  // weights: the host passes those weights embedded in a 3x3 window (5 zero taps), `tap_mask` names the 4 live taps --
+  // the others skip their fragment reads and MFMAs --, the output is written with pixel stride 2 at offset (ooy, oox)
+  // into the [N][2H][2W][Cout] tensor, and the fused statistics go to slab (tile * 4 + slab_off) of 4 x as many slabs
+  int tap_mask, ooy, oox, slab_off;
 };
 
 // output-statistics slabs per tile: a 128-pixel tile is two 8x8 images (or two halves of one image)
@@ -154,11 +160,13 @@ conv_kernel(const ConvK p) {
   constexpr int SEGSH = KS == 1 ? 2 : 3;   // log2(SEGP)
   constexpr int ROWB = conv_rowb(KS);      // LDS bytes per halo pixel
   constexpr int PASSES = (HALO * SEGP + NT - 1) / NT;
-  constexpr int PAD = TAPS == 9 ? 1 : 0;
+  constexpr bool T3 = TAPS == 9 || TAPS == 4;   // 3x3 geometry; TAPS == 4: an up-conv phase (4 of the 9 taps live)
+  constexpr bool UPPH = TAPS == 4;
+  constexpr int PAD = T3 ? 1 : 0;
   constexpr int SGROUPS = stat_groups<BM>();  // statistics slabs per tile
   using Lds = ConvLds<NT, BN, HALO, BM, KS>;
   static_assert(KS == 1 || (KS == 2 && TAPS == 1), "multi-step stages are a 1x1 feature");
-  static_assert(TAPS == 1 || PASSES <= TAPS - 1, "halo passes must fit in the taps of one chunk");
+  static_assert(TAPS == 1 || PASSES <= (T3 ? 9 : TAPS) - 1, "halo passes must fit in the taps of one chunk");
   static_assert(PASSES <= 8, "ti_pack holds 8 passes");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -400,13 +408,13 @@ conv_kernel(const ConvK p) {
   // The narrow register loads (first weight fragments: 3x3 ring of 3 K-steps, two in flight; 1x1 ring of
   // 4, three in flight, plus the activation segments of chunk 1; the bias fragment the accumulators start
   // from) go out once the accumulators' registers are free.
-  constexpr int WRING = TAPS == 9 ? 3 : (KS == 1 ? 4 : 2 * KS);
+  constexpr int WRING = T3 ? 3 : (KS == 1 ? 4 : 2 * KS);
   uint4 wr[WRING][TN];
   uint4 ring[ADM_CONV_RD][PASSES];
   float4 bs[TN];
   const int last = chunks - 1;
   auto first_loads = [&](int lq_) {
-    if constexpr (TAPS == 9) {
+    if constexpr (T3) {
       load_w(cb * 9, wr[0]);
       load_w(cb * 9 + 1, wr[1]);
     } else {
@@ -462,7 +470,7 @@ conv_kernel(const ConvK p) {
 
     const int tnext = tl + gx;
     const bool more = tnext < tcount;
-    if constexpr (TAPS == 9) {
+    if constexpr (T3) {
       // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
       auto chunk = [&](int c, auto more_) {
         constexpr bool MORE = decltype(more_)::value;
@@ -492,7 +500,8 @@ conv_kernel(const ConvK p) {
             if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
           }
           hprev = hcur;
-          mfma_tap(halo + hb * Lds::HB + ((t / 3) * HW2 + (t % 3)) * ROWB, wr[t % 3]);
+          if (!UPPH || ((p.tap_mask >> t) & 1))   // up-conv phase: 5 of the 9 taps carry zero weights (wave-uniform skip)
+            mfma_tap(halo + hb * Lds::HB + ((t / 3) * HW2 + (t % 3)) * ROWB, wr[t % 3]);
         }
         __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
       };
@@ -604,7 +613,9 @@ conv_kernel(const ConvK p) {
       const int thw_mask = (1 << p.thw_shift) - 1, tw_mask = (1 << p.tw_shift) - 1;
       // (a) this tile's output / residual bases and statistics destinations (the per-row offsets follow the
       // tile switch: they only need the first image of the finished tile)
-      const long long ebase = (((long long)img0 * p.H + y0) * p.W + x0) * p.Cout + gch;  // element offset of the tile origin
+      // element offset of the tile origin (up-conv phase: output map 2H x 2W, this phase's pixels at stride 2)
+      const long long ebase = UPPH ? (((long long)img0 * (2 * p.H) + 2 * y0 + p.ooy) * (2 * p.W) + 2 * x0 + p.oox) * p.Cout + gch
+                                   : (((long long)img0 * p.H + y0) * p.W + x0) * p.Cout + gch;
       uint16_t* const obase = reinterpret_cast<uint16_t*>(p.out) + ebase;
       // residual through a virtual 2x upsample: source map (H/2) x (W/2); tile origins are even
       const int Hr = p.H >> p.res_up, Wr = p.W >> p.res_up;
@@ -615,7 +626,7 @@ conv_kernel(const ConvK p) {
       for (int g = 0; g < SGROUPS; ++g) {
         const int n = img0 + ((g * RG) >> p.thw_shift);
         // slab of this group inside its image: (tile of the image) * SGROUPS + g for one-image tiles
-        const int slab = p.TI == 1 ? (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g : 0;
+        const int slab = p.TI == 1 ? (UPPH ? (mt % (p.tiles_x * p.tiles_y)) * 4 + p.slab_off : (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g) : 0;
         sdst[g] = (p.stats && tid_e < BN && nb * BN + tid_e < p.Cout && n < p.N)
                       ? p.stats + (((long long)n * p.stat_slabs + slab) * p.Cout + nb * BN + tid_e) * 2 : nullptr;
       }
@@ -648,7 +659,10 @@ conv_kernel(const ConvK p) {
         for (int k = 0; k < NIT; ++k) {
           const int ml = prow + k * PR, m = g * RG + ml;
           const int ti = m >> p.thw_shift, rem = m & thw_mask;
-          eoff[g][k] = (act && ml < RG && img0_d + ti < p.N) ? ((ti * p.H + (rem >> p.tw_shift)) * p.W + (rem & tw_mask)) * p.Cout : -1;
+          eoff[g][k] = (act && ml < RG && img0_d + ti < p.N)
+                           ? (UPPH ? ((rem >> p.tw_shift) * (4 * p.W) + 2 * (rem & tw_mask)) * p.Cout   // TI == 1: rows of the 2W-wide map, 2 apart
+                                   : ((ti * p.H + (rem >> p.tw_shift)) * p.W + (rem & tw_mask)) * p.Cout)
+                           : -1;
         }
       ADM_TSTAMP(ltile_done, 12);
       uint4 rr[SGROUPS][NIT];
@@ -1211,6 +1225,9 @@ int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
     if constexpr (BM == 256) {
       if (conv_geometry(k, BM, 9, 324) && k.TI == 1) {
         const int m_tiles = k.N * k.tiles_x * k.tiles_y;
+        if constexpr (WN == 4) {   // up-conv phase launches exist for the 8-wave tilings only
+          if (k.tap_mask != 0x1ff) return launch_conv<WM, WN, TM, TN, OCC, 4, 324, 1>(k, prologue, m_tiles, s);
+        }
         return launch_conv<WM, WN, TM, TN, OCC, 9, 324, 1>(k, prologue, m_tiles, s);
       }
     } else {
@@ -1248,6 +1265,7 @@ int pick_variant(const adm_conv_args* a) {
 int stat_slabs_for(const adm_conv_args* a, int variant) {
   if (a->out_mode != 0 || variant == 7) return 0;
   const int hw = a->h * a->w;
+  if (a->up_phase) return (a->h >= 16 && a->w >= 16 && hw % 256 == 0) ? hw / 256 * 4 : 0;   // one slab per (source tile, phase)
   if (hw <= 64) return hw == 64 ? 1 : 0;
   if (a->h < 16 || a->w < 16 || hw % 256 != 0) return 0;
   return hw / 256;
@@ -1344,6 +1362,20 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE(!(k.in_up || k.res_up) || (a->taps == 9 && a->out_mode == 0 && a->c1 == 0 && a->h % 2 == 0 && a->w % 2 == 0 && a->h >= 16 && a->w >= 16),
               ADM_E_SHAPE, "adm_conv: in_up / res_up need a 3x3 conv with bf16 output, one input source and an even map >= 16x16");
   ADM_REQUIRE(!k.res_up || a->res, ADM_E_ARG, "adm_conv: res_up without a residual operand");
+  k.tap_mask = 0x1ff; k.ooy = 0; k.oox = 0; k.slab_off = 0;
+  if (a->up_phase) {
+    // phase (py, px) = up_phase - 1: out[2y + py][2x + px] = sum over the source window rows {y - 1 + py, y + py} x columns
+    // {x - 1 + px, x + px}: taps (ky, kx) in {py, py + 1} x {px, px + 1} of the 3x3 window around source pixel (y, x)
+    ADM_REQUIRE(a->up_phase >= 1 && a->up_phase <= 4, ADM_E_ARG, "adm_conv: up_phase must be 0 or 1..4");
+    ADM_REQUIRE(a->taps == 9 && a->out_mode == 0 && a->c1 == 0 && !a->res && !a->in_up && !a->res_up && a->ksplit <= 1 &&
+                a->h >= 16 && a->w >= 16, ADM_E_SHAPE,
+                "adm_conv: up_phase needs a 3x3 conv with bf16 output, one source >= 16x16, no residual / split-K / in_up");
+    const int py = (a->up_phase - 1) >> 1, px = (a->up_phase - 1) & 1;
+    k.tap_mask = 0;
+    for (int ky = py; ky <= py + 1; ++ky)
+      for (int kx = px; kx <= px + 1; ++kx) k.tap_mask |= 1 << (ky * 3 + kx);
+    k.ooy = py; k.oox = px; k.slab_off = a->up_phase - 1;
+  }
   k.ksplit = a->ksplit > 1 ? a->ksplit : 1;
   k.cps = 0;
   k.ws = a->ws;
@@ -1370,7 +1402,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     k.res = nullptr;      // bias, residual and statistics belong to the reduce pass
     k.stats = nullptr;
   }
-  ADM_REQUIRE(!(k.in_up || k.res_up) || variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: in_up / res_up need tiling variant 5 or 6");
+  ADM_REQUIRE(!(k.in_up || k.res_up || a->up_phase) || variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: in_up / res_up / up_phase need tiling variant 5 or 6");
   if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
     ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out");
     ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1, ADM_E_SHAPE, "adm_conv: variant 7 needs maps >= 16x16");

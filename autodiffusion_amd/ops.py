@@ -8,6 +8,7 @@ the hot path; if the shared library is missing these functions raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -224,6 +225,29 @@ def pack_conv_weight(w, dtype=BF16):
     return out
 
 
+UPCONV_PHASES = os.environ.get("ADM_UPCONV_PHASES", "1") != "0"   # conv3x3(upsample2x(x)) as four 2x2-tap phase convs (4/9 of the MACs)
+
+
+def pack_conv_weight_up(w, dtype=BF16):
+    """The four phase weights of conv3x3(nearest-upsample-2x(x), w) (adm_conv_args.up_phase): for output pixels
+    (2y + py, 2x + px) the nine taps collapse onto a 2x2 window of the half-resolution source -- rows {y-1, y} carry
+    {w0, w1 + w2} for py = 0 and rows {y, y+1} carry {w0 + w1, w2} for py = 1, likewise for columns -- summed in fp32 and
+    embedded in a 3x3 window around (y, x) (5 zero taps, skipped by the kernel).  Returns a [4, elems] packed tensor."""
+    w32 = w.detach().to(torch.float32)
+    rows = {0: [[0], [1, 2], []], 1: [[], [0, 1], [2]]}   # window row r <- original taps, by phase
+    packed = []
+    for ph in range(4):
+        py, px = ph >> 1, ph & 1
+        wp = torch.zeros_like(w32)
+        for r in range(3):
+            for c in range(3):
+                for ky in rows[py][r]:
+                    for kx in rows[px][c]:
+                        wp[:, :, r, c] += w32[:, :, ky, kx]
+        packed.append(pack_conv_weight(wp, dtype))
+    return torch.stack(packed, 0).contiguous()
+
+
 def pack_conv_weight32(w, dtype=BF16):
     """Same weight in the 32x32x16 fragment order (enables adm_conv's variant 7)."""
     cout, cin = w.shape[0], w.shape[1]
@@ -253,15 +277,20 @@ def splitk_for(h: int, w: int, cin: int) -> int:
 
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
-         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1):
+         out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1,
+         w_up=None):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): 16-bit NHWC (bf16, or fp16 for an fp16-torso model: the library is picked by x0's dtype).  Returns the same
     type NHWC [n,h,w,cout] or fp32 NCHW [n,cout,h,w].  ksplit > 1: split-K schedule for small batches (see splitk_for).
     in_up / res_up: x0 / res are at half resolution and are read through a virtual nearest-neighbour 2x upsample
-    (the output is [n, 2h, 2w, cout]): ResBlock(up=True) without materialising the upsampled tensors.
+    (the output is [n, 2h, 2w, cout]): ResBlock(up=True) without materialising the upsampled tensors.  With w_up
+    (pack_conv_weight_up) an in_up conv runs as four phase launches of 2x2 live taps each (4/9 of the MACs).
     """
     n, h, w, c0 = x0.shape
+    if (in_up and w_up is not None and UPCONV_PHASES and taps == 9 and x1 is None and res is None and not res_up
+            and not out_f32_nchw and ksplit <= 1 and h >= 16 and w >= 16 and (h * w) % 256 == 0 and variant == 0):
+        return _conv_up_phases(x0, w_up, bias, cout, aff, silu, out, want_stats)
     if in_up:
         h, w = 2 * h, 2 * w
     c1 = 0 if x1 is None else x1.shape[3]
@@ -313,6 +342,45 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
                              (n, h, w, c0 + c1, cout)))
         return out
     check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
+    return out
+
+
+def _conv_up_phases(x0, w_up, bias, cout, aff, silu, out, want_stats):
+    """conv3x3(upsample2x(x0)) as four adm_conv launches with up_phase = 1..4 (include/adm_hip.h): x0 is the
+    half-resolution source [n, h, w, c0], the result [n, 2h, 2w, cout]."""
+    n, h, w, c0 = x0.shape
+    dev = x0.device
+    lib = _L(x0)
+    if out is None:
+        out = torch.empty((n, 2 * h, 2 * w, cout), dtype=x0.dtype, device=dev)
+    a = ConvArgs()
+    a.in0, a.bias = _ptr(x0, x0.dtype, "x0"), _ptr(bias, torch.float32, "bias")
+    if aff is not None:
+        a.aff_a, a.aff_b = _ptr(aff[0], torch.float32, "aff_a"), _ptr(aff[1], torch.float32, "aff_b")
+        a.prologue = 2 if silu else 1
+    a.out = _ptr(out)
+    a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, 0, cout
+    a.taps, a.out_mode, a.up_phase = 9, 0, 1
+    a.w_packed = _ptr(w_up[0], x0.dtype, "w_up")
+    variant = a.variant = lib.adm_conv_pick_variant(C.byref(a))
+    if want_stats and USE_FUSED_STATS:
+        slabs = lib.adm_conv_stat_slabs(C.byref(a))
+        if slabs > 0:
+            fused = (torch.empty((n, slabs, cout, 2), dtype=torch.float32, device=dev), slabs)
+            a.out_stats = fused[0].data_ptr()
+            out._adm_stats = fused
+    prof = CONV_PROFILE is not None and (CONV_PROFILE_KEY is None or CONV_PROFILE_KEY == (variant, 4, True, a.prologue))
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    for ph in range(4):
+        a.up_phase = ph + 1
+        a.w_packed = _ptr(w_up[ph], x0.dtype, "w_up")
+        check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
+    if prof:
+        e1.record()
+        # algorithmic work of the layer as the reference states it: a 9-tap conv on the upsampled map
+        CONV_PROFILE.append((e0, e1, 2.0 * n * 4 * h * w * cout * c0 * 9, (variant, 4, True, a.prologue), (n, 2 * h, 2 * w, c0, cout)))
     return out
 
 

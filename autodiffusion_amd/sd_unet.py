@@ -131,7 +131,8 @@ class UNetModel(HipModule):
                 pr.blocks[p] = dict(w=pack(P[f"{p}.op.weight"]), b=f32(f"{p}.op.bias"),
                                     w2d=ops.pack_conv2d_weight(P[f"{p}.op.weight"], None, self.compute_dtype))   # real stride-2 taps (adm_conv2d)
             elif isinstance(b, SDUpSpec):
-                pr.blocks[p] = dict(w=pack(P[f"{p}.conv.weight"]), b=f32(f"{p}.conv.bias"))
+                pr.blocks[p] = dict(w=pack(P[f"{p}.conv.weight"]), b=f32(f"{p}.conv.bias"),
+                                    w_up=ops.pack_conv_weight_up(P[f"{p}.conv.weight"], self.compute_dtype))
             elif isinstance(b, SDTransformerSpec):
                 h, dh, dp = b.heads, b.d_head, _padded_head(b.d_head)
                 d = dict(g=f32(f"{p}.norm.weight"), b=f32(f"{p}.norm.bias"), dp=dp,
@@ -227,7 +228,10 @@ class UNetModel(HipModule):
                 else:              # stride-1 conv + every-second-pixel pick: 4 x the MACs on the faster tile kernel
                     h = ops.resample(ops.conv(h, d["w"], d["b"], blk.channels, 9), "stride2")
             elif isinstance(blk, SDUpSpec):
-                h = ops.conv(h, d["w"], d["b"], blk.channels, 9, in_up=True, want_stats=True)
+                # four 2x2-tap phase launches pay off once a launch has a few hundred tiles (batch >= ~48 latents); at the
+                # search's 6-latent half batches the one-launch virtual upsample is 1.4-2.5 x faster (tools/upconv_bench.py)
+                h = ops.conv(h, d["w"], d["b"], blk.channels, 9, in_up=True, want_stats=True,
+                             w_up=d["w_up"] if self.upconv_phases else None)
             else:
                 raise TypeError(blk)
             first = False
@@ -237,6 +241,14 @@ class UNetModel(HipModule):
     use_graph = False  # replay one captured hipGraph per input shape (set by .enable_graph())
 
     small_batch_splitk = False  # split the K loop of the 8x8 / 16x16-level 3x3 convs (set by .enable_splitk())
+    upconv_phases = False       # Upsample convs as four 2x2-tap phase launches (large batches only; .enable_upconv_phases())
+
+    def enable_upconv_phases(self, on: bool = True):
+        self.upconv_phases = bool(on)
+        if self._packed is not None:
+            self._packed.graphs = {}
+        return self
+
 
     def enable_splitk(self, flag: bool = True):
         """For the search's batch (n_samples 6, i.e. 6-latent half batches under guidance): the 3x3 convs of the 8x8 and

@@ -210,6 +210,11 @@ class AdmNet(HipModule):
     # evaluation once per (entry point, input shapes, layer-skip set, launching stream) and replays it: bit-identical
     # outputs.  Graphs (with their private allocator pools) live in the packed-weight object and die with it; at most
     # GRAPH_CACHE of them are kept (layer-skip candidates bring a new launch sequence per distinct skip list).
+    # up-ResBlocks: conv3x3(upsample2x(.)) as four 2x2-tap phase convs on the half-resolution tensor (4/9 of the MACs; x 1.5
+    # at batch 256, tools/upconv_bench.py).  A per-model choice, never a function of the batch: the pre-summed taps round
+    # differently from the nine separate ones, and an image's result must not depend on how many ride along.
+    upconv_phases = ops.UPCONV_PHASES
+
     use_graph = False
     GRAPH_CACHE = 12
 
@@ -288,6 +293,8 @@ class AdmNet(HipModule):
                 if b.has_skip_conv:
                     d["ws"] = pack(P[f"{p}.skip_connection.weight"])
                     d["wsb"] = f32(f"{p}.skip_connection.bias")
+                elif b.up:   # up-ResBlock: the first conv reads a 2x upsample -> four 2x2-tap phase convs (ops.pack_conv_weight_up)
+                    d["w1_up"] = ops.pack_conv_weight_up(P[f"{p}.in_layers.2.weight"], cd)
                 pr.blocks[p] = d
             elif isinstance(b, AttnSpec):
                 pr.blocks[p] = dict(
@@ -345,7 +352,8 @@ class AdmNet(HipModule):
             # h_upd(in_layers[:-1](x)) and x_upd(x) are never materialised: both convs read the half-resolution
             # tensor through a nearest-neighbour 2x upsample (adm_conv_args.in_up / res_up)
             assert x1 is None
-            h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, aff=aff1, silu=True, in_up=True, want_stats=True)
+            h = ops.conv(x0, d["w1"], d["c1b"], s.cout, 9, aff=aff1, silu=True, in_up=True, want_stats=True,
+                         w_up=d.get("w1_up") if self.upconv_phases else None)
             xs, xs1 = x0, None
         elif mode:
             assert x1 is None

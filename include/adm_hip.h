@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 4   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points */
+#define ADM_ABI_VERSION 5   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -166,6 +166,14 @@ typedef struct adm_conv_args {
                         tiles into `ws`, and a reduce pass adds them in index order with bias, residual and the output
                         statistics.  Deterministic; the result depends on ksplit (fp32 summation order), not on n */
   float* ws;         /* split-K workspace: fp32 [ksplit][n*h*w][cout], caller-owned */
+  int32_t up_phase;  /* 1..4 = phase (py, px) = ((up_phase-1) >> 1, (up_phase-1) & 1) of conv3x3(nearest-upsample-2x(in0)): in0 is
+                        the half-resolution [n][h][w][c0] source, `out` the [n][2h][2w][cout] tensor of which this launch writes
+                        the pixels (2y + py, 2x + px).  Each phase is a 2x2-tap conv of the source: w_packed holds its pre-summed
+                        weights embedded in a 3x3 window (adm_pack_conv_weight of the host-made 3x3 tensor: rows {w0, w1 + w2, 0}
+                        for py = 0, {0, w0 + w1, w2} for py = 1, likewise for columns); the 5 zero taps are skipped: 4/9 of the
+                        MACs of in_up = 1.  Four launches (one per phase) replace one in_up conv; out_stats then has
+                        adm_conv_stat_slabs = 4 x (h / 16) x (w / 16) slabs, each launch filling its quarter.  3x3, bf16 output,
+                        c1 == 0, no residual, source >= 16x16, variant 0/5/6                                                    */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

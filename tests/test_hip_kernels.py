@@ -257,6 +257,42 @@ def test_conv_virtual_upsample(ops, n, hs, cin, cout, prologue, in_up, res_up):
     assert_close_bf16(nchw_cpu(got), ref, f"virtual upsample {n, hs, cin, cout, prologue, in_up, res_up}")
 
 
+@pytest.mark.parametrize("n,hs,ws,cin,cout,prologue", [(3, 16, 16, 192, 192, 2), (2, 32, 32, 384, 384, 2), (2, 16, 32, 256, 256, 2),
+                                                       (5, 16, 16, 64, 320, 0), (1, 32, 16, 128, 136, 1)])
+def test_conv_upsample_as_four_phase_convs(ops, n, hs, ws, cin, cout, prologue):
+    """conv3x3(nearest-upsample-2x(act(GN(x)))) as four 2x2-tap phase launches (adm_conv_args.up_phase, ops.pack_conv_weight_up):
+    against the PyTorch-CPU reference of the op and against the one-launch virtual-upsample path, incl. the fused output
+    statistics (per-image sums over all slabs) that the next GroupNorm consumes."""
+    x = bf(rnd((n, cin, hs, ws), 1))
+    w = rnd((cout, cin, 3, 3), 2, (cin * 9) ** -0.5)
+    b = rnd((cout,), 3, 0.1)
+    a_, b_ = 1 + 0.2 * rnd((n, cin), 4), 0.2 * rnd((n, cin), 5)
+    h = x
+    if prologue:
+        h = a_[:, :, None, None] * x + b_[:, :, None, None]
+        if prologue == 2:
+            h = F.silu(h)
+    ref = F.conv2d(F.interpolate(bf(h), scale_factor=2, mode="nearest"), bf(w), b, padding=1)
+    aff = (a_.to(DEV), b_.to(DEV)) if prologue else None
+    wd = w.to(DEV)
+    one = ops.conv(nhwc_dev(x), ops.pack_conv_weight(wd), b.to(DEV), cout, 9, aff=aff, silu=(prologue == 2), in_up=True, want_stats=True)
+    four = ops.conv(nhwc_dev(x), ops.pack_conv_weight(wd), b.to(DEV), cout, 9, aff=aff, silu=(prologue == 2), in_up=True, want_stats=True,
+                    w_up=ops.pack_conv_weight_up(wd))
+    assert four.shape == (n, 2 * hs, 2 * ws, cout) and ops.UPCONV_PHASES
+    # pre-summed taps are rounded to bf16 once (w1 + w2) instead of twice: the same size of error as the reference's own rounding
+    got = nchw_cpu(four)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-2 * scale and ((got - ref).norm() / ref.norm()).item() <= 6e-3
+    assert ((got - nchw_cpu(one)).norm() / ref.norm()).item() <= 6e-3
+    # fused statistics: 4 x as many slabs, each phase launch fills its quarter; totals = sums over the stored output
+    st4, slabs4 = four._adm_stats
+    assert slabs4 == 4 * (hs * ws // 256) and st4.shape == (n, slabs4, cout, 2)
+    tot = st4.sum(1).cpu()
+    f32o = four.float().cpu()
+    torch.testing.assert_close(tot[..., 0], f32o.sum((1, 2)), rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(tot[..., 1], (f32o * f32o).sum((1, 2)), rtol=2e-3, atol=2e-2)
+
+
 def test_conv_random_shapes(ops):
     """Seeded sweep over shapes the fixed cases do not list: batch sizes that leave ragged tiles, virtual concat splits,
     Cout that pads the 192/128-wide blocks, 3x3 and 1x1 (staged and resident-tile kernels), every prologue, residual and
