@@ -25,6 +25,7 @@ from .unet import AdmNet
 
 class EncoderUNetModel(AdmNet):
     with_backward = True
+    fuse_gn_bwd = ops.FUSE_GN_BWD   # a per-model choice (never by batch): the fused sums are taken per 256-pixel tile
 
     def __init__(self, plan: UNetPlan, use_fp16: bool = False):
         if not plan.encoder_only or not isinstance(plan.head, AttnPoolSpec):
@@ -129,16 +130,28 @@ class EncoderUNetModel(AdmNet):
                     g = ops.gn_bwd(t["x"], dgn, t["aff"], t["st"], silu=False, add=g)
                 elif kind == "res":
                     d = pr.blocks[s.prefix]
-                    d_act2 = self._bwd_conv(pr, g, d["w2_bwd"], s.cout, 9)
-                    dh1 = ops.gn_bwd(t["h1"], d_act2, t["aff2"], t["st2"], silu=True)
-                    d_in = self._bwd_conv(pr, dh1, d["w1_bwd"], s.cin, 9)
+                    # on maps >= 16x16 the backward conv's epilogue already turns its output into dz = dy * SiLU'(a x + b) and
+                    # leaves the (sum dz, sum dz x) slabs: the GroupNorm backward then is finalize + apply, no partial pass
+                    fuse2 = self.fuse_gn_bwd and _gnb_ok(t["h1"])
+                    if fuse2:
+                        dz2 = ops.conv(g, d["w2_bwd"], pr.zero_bias, s.cout, 9, gnb=(t["h1"], t["aff2"]))
+                        dh1 = ops.gn_bwd(t["h1"], dz2, t["aff2"], t["st2"], silu=True, partial=dz2._adm_stats[0])
+                    else:
+                        d_act2 = self._bwd_conv(pr, g, d["w2_bwd"], s.cout, 9)
+                        dh1 = ops.gn_bwd(t["h1"], d_act2, t["aff2"], t["st2"], silu=True)
                     if s.down:
+                        d_in = self._bwd_conv(pr, dh1, d["w1_bwd"], s.cin, 9)
                         g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, dy_half=True, add=g, add_half=True)
                     elif s.up:
                         raise NotImplementedError("up-sampling ResBlocks do not occur in the encoder")
                     else:
                         dskip = self._bwd_conv(pr, g, d["ws_bwd"], s.cin, 1) if s.has_skip_conv else g
-                        g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, add=dskip)
+                        if self.fuse_gn_bwd and _gnb_ok(t["x"]):
+                            dz1 = ops.conv(dh1, d["w1_bwd"], pr.zero_bias, s.cin, 9, gnb=(t["x"], t["aff1"]))
+                            g = ops.gn_bwd(t["x"], dz1, t["aff1"], t["st1"], silu=True, add=dskip, partial=dz1._adm_stats[0])
+                        else:
+                            d_in = self._bwd_conv(pr, dh1, d["w1_bwd"], s.cin, 9)
+                            g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, add=dskip)
                 elif kind == "stem":
                     d = pr.blocks[s.prefix]
                     g = ops.conv(g, d["w_bwd"], pr.zero_bias, s.cin, 9, out_f32_nchw=True)
@@ -161,6 +174,12 @@ class EncoderUNetModel(AdmNet):
         with torch.no_grad():
             dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale)
         return self._backward_tape(tape, dl), logits
+
+
+def _gnb_ok(x) -> bool:
+    """A GroupNorm input whose backward-data conv can carry the GroupNorm-backward epilogue (adm_conv prologue 3)."""
+    _, h, w, c = x.shape
+    return h >= 16 and w >= 16 and (h * w) % 256 == 0 and c % 8 == 0
 
 
 class _ClassifierFn(torch.autograd.Function):

@@ -147,9 +147,15 @@ __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned vo
 // dependent latencies) or the block launch gap; here the NEXT tile's first loads are issued before the
 // current tile's accumulators are staged and stored, and land in LDS (halo buffer 0, which the output
 // staging does not overlay) while the epilogue runs.
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO, int KS>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PROX, int KS>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 conv_kernel(const ConvK p) {
+  // PROX 0..2 = the prologue; 3 = a raw input (backward-data conv) whose EPILOGUE is the first half of the GroupNorm(+SiLU)
+  // backward of the layer in front (adm_conv_args.prologue == 3): with x = that layer's input (`res`) and its affine (a, b),
+  // out = dz = acc * SiLU'(a x + b), statistics = (sum dz, sum dz * x) per (image, slab, channel) -- the partial sums the
+  // separate adm_gn_bwd_partial pass would re-read x and dy for
+  constexpr int PRO = PROX == 3 ? 0 : PROX;
+  constexpr bool GNB = PROX == 3;
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
@@ -680,6 +686,19 @@ conv_kernel(const ConvK p) {
             rr[g][k] = *reinterpret_cast<const uint4*>(rbase + roff);
           }
         }
+      [[maybe_unused]] float ga[8], gb[8];   // GNB: affine of this thread's 8 channels in the finished tile's image (TI == 1)
+      if constexpr (GNB) {
+        const long long ao = (long long)img0_d * p.Cout + gch;
+        if (act) {
+          *reinterpret_cast<float4*>(ga) = *reinterpret_cast<const float4*>(p.aa + ao);
+          *reinterpret_cast<float4*>(ga + 4) = *reinterpret_cast<const float4*>(p.aa + ao + 4);
+          *reinterpret_cast<float4*>(gb) = *reinterpret_cast<const float4*>(p.ab + ao);
+          *reinterpret_cast<float4*>(gb + 4) = *reinterpret_cast<const float4*>(p.ab + ao + 4);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { ga[e] = 0.f; gb[e] = 0.f; }
+        }
+      }
       if (more) first_loads((tid_e & 63) >> 4);
       ADM_TSTAMP(ltile_done, 13);
       __syncthreads();
@@ -701,7 +720,21 @@ conv_kernel(const ConvK p) {
           if (eoff[g][k] < 0) continue;
           uint4 v = *reinterpret_cast<const uint4*>(stg + (g * RG + prow + k * PR) * EROW + sg * 16);
           uint32_t a4[4] = {v.x, v.y, v.z, v.w};
-          if (rbase) {
+          [[maybe_unused]] f32x2 xg[4];
+          if constexpr (GNB) {
+            // dz = dy * SiLU'(a x + b), SiLU'(z) = s (1 + z (1 - s)), s = sigmoid(z); x rides in the residual registers
+            const uint32_t r4[4] = {rr[g][k].x, rr[g][k].y, rr[g][k].z, rr[g][k].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              xg[q] = f32x2{adm_lo_f32(r4[q]), adm_hi_f32(r4[q])};
+              const f32x2 z = f32x2{ga[2 * q], ga[2 * q + 1]} * xg[q] + f32x2{gb[2 * q], gb[2 * q + 1]};
+              const f32x2 sgm = f32x2{__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z.x * -1.4426950408889634f)),
+                                      __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z.y * -1.4426950408889634f))};
+              const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])} * (sgm * (1.0f + z * (1.0f - sgm)));
+              a4[q] = adm_pack2(t.x, t.y);
+            }
+            v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+          } else if (rbase) {
             const uint32_t r4[4] = {rr[g][k].x, rr[g][k].y, rr[g][k].z, rr[g][k].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -719,7 +752,8 @@ conv_kernel(const ConvK p) {
           for (int q = 0; q < 4; ++q) {
             const f32x2 t = f32x2{adm_lo_f32(a4[q]), adm_hi_f32(a4[q])};
             s1[g][q] += t;
-            s2[g][q] = __builtin_elementwise_fma(t, t, s2[g][q]);
+            if constexpr (GNB) s2[g][q] = __builtin_elementwise_fma(t, xg[q], s2[g][q]);   // sum dz * x
+            else s2[g][q] = __builtin_elementwise_fma(t, t, s2[g][q]);
           }
         }
       ADM_TSTAMP(ltile_done, 5);
@@ -1193,6 +1227,9 @@ int launch_conv(const ConvK& k, int prologue, int m_tiles, hipStream_t s) {
   switch (prologue) {
     case 0: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 0, KS>(k, m_tiles, s);
     case 1: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 1, KS>(k, m_tiles, s);
+    case 3:   // GroupNorm-backward epilogue: 3x3 backward-data convs on the 256-pixel 8-wave tiles only
+      if constexpr (TAPS == 9 && HALO == 324 && WN == 4) return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 3, KS>(k, m_tiles, s);
+      else ADM_FAIL(ADM_E_SHAPE, "adm_conv: prologue 3 (GroupNorm-backward epilogue) needs a 3x3 conv on a map >= 16x16");
     default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2, KS>(k, m_tiles, s);
   }
 }
@@ -1334,7 +1371,10 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   ADM_REQUIRE(a->in0 && a->w_packed && a->bias && a->out, ADM_E_ARG, "adm_conv: null pointer");
   ADM_REQUIRE((a->in1 != nullptr) == (a->c1 > 0), ADM_E_ARG, "adm_conv: in1/c1 mismatch");
   ADM_REQUIRE(a->taps == 1 || a->taps == 9, ADM_E_ARG, "adm_conv: taps must be 1 or 9");
-  ADM_REQUIRE(a->prologue >= 0 && a->prologue <= 2, ADM_E_ARG, "adm_conv: prologue must be 0..2");
+  ADM_REQUIRE(a->prologue >= 0 && a->prologue <= 3, ADM_E_ARG, "adm_conv: prologue must be 0..3");
+  ADM_REQUIRE(a->prologue != 3 || (a->res && a->out_stats && a->taps == 9 && a->out_mode == 0 && !a->in_up && !a->res_up &&
+                                   a->ksplit <= 1 && !a->up_phase && a->h >= 16 && a->w >= 16 && (a->h * a->w) % 256 == 0 && a->cout % 8 == 0),
+              ADM_E_ARG, "adm_conv: prologue 3 (GroupNorm-backward epilogue) needs res (= x), out_stats, a 3x3 conv with bf16 output on a map >= 16x16");
   ADM_REQUIRE(a->out_mode == 0 || a->out_mode == 1, ADM_E_ARG, "adm_conv: out_mode must be 0 or 1");
   ADM_REQUIRE((a->prologue == 0) || (a->aff_a && a->aff_b), ADM_E_ARG, "adm_conv: prologue needs aff_a/aff_b");
   ADM_REQUIRE(a->out_mode == 0 || !a->res, ADM_E_ARG, "adm_conv: residual only with bf16 NHWC output");

@@ -225,6 +225,7 @@ def pack_conv_weight(w, dtype=BF16):
     return out
 
 
+FUSE_GN_BWD = os.environ.get("ADM_FUSE_GN_BWD", "1") != "0"   # GroupNorm-backward partial sums in the producing backward conv's epilogue
 UPCONV_PHASES = os.environ.get("ADM_UPCONV_PHASES", "1") != "0"   # conv3x3(upsample2x(x)) as four 2x2-tap phase convs (4/9 of the MACs)
 
 
@@ -278,7 +279,7 @@ def splitk_for(h: int, w: int, cin: int) -> int:
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
          out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1,
-         w_up=None):
+         w_up=None, gnb=None):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): 16-bit NHWC (bf16, or fp16 for an fp16-torso model: the library is picked by x0's dtype).  Returns the same
@@ -302,7 +303,18 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     lib = _L(x0)
     a.in0, a.in1 = _ptr(x0, x0.dtype, "x0"), _ptr(x1, x0.dtype, "x1")
     a.w_packed, a.bias = _ptr(w_packed, x0.dtype, "w_packed"), _ptr(bias, torch.float32, "bias")
-    if aff is not None:
+    if gnb is not None:
+        # backward-data conv whose epilogue is the first half of the GroupNorm + SiLU backward of the layer in front:
+        # gnb = (x, (a, b)) of that layer; the result is dz = conv(...) * SiLU'(a x + b) with out._adm_stats = (sum dz, sum dz x)
+        if aff is not None or res is not None or taps != 9 or out_f32_nchw or in_up or res_up or ksplit > 1:
+            raise AdmError("conv(gnb=...): a raw 3x3 backward-data conv with bf16 output")
+        gx, (ga, gb_) = gnb
+        if tuple(gx.shape) != (n, h, w, cout):
+            raise AdmError(f"conv(gnb=...): x {tuple(gx.shape)} must have the output's shape {(n, h, w, cout)}")
+        a.aff_a, a.aff_b = _ptr(ga, torch.float32, "gnb a"), _ptr(gb_, torch.float32, "gnb b")
+        a.prologue = 3
+        res, want_stats = gx, True
+    elif aff is not None:
         a.aff_a, a.aff_b = _ptr(aff[0], torch.float32, "aff_a"), _ptr(aff[1], torch.float32, "aff_b")
         a.prologue = 2 if silu else 1
     else:
@@ -327,12 +339,14 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
             variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
         a.variant = variant
     fused = None
-    if want_stats and USE_FUSED_STATS:
+    if want_stats and (USE_FUSED_STATS or gnb is not None):
         slabs = lib.adm_conv_stat_slabs(C.byref(a))
         if slabs > 0:
             fused = (torch.empty((n, slabs, cout, 2), dtype=torch.float32, device=dev), slabs)
             a.out_stats = fused[0].data_ptr()
             out._adm_stats = fused
+        elif gnb is not None:
+            raise AdmError("conv(gnb=...): the map does not offer fused statistics (needs >= 16x16, pixels % 256 == 0)")
     if CONV_PROFILE is not None and (CONV_PROFILE_KEY is None or CONV_PROFILE_KEY == (variant, taps, h * w > 64, a.prologue)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -443,23 +457,32 @@ def attention_bwd(qkv, out, dout, lse, heads: int, new_order: bool):
     return dqkv
 
 
-def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=False):
-    """Backward of y = act(a*x+b) (GroupNorm(+FiLM)(+SiLU)): returns dx bf16 NHWC (+ add)."""
+def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=False, partial=None):
+    """Backward of y = act(a*x+b) (GroupNorm(+FiLM)(+SiLU)): returns dx bf16 NHWC (+ add).
+
+    partial: the producing backward-data conv already wrote dz = dy * SiLU'(a x + b) and its (sum dz, sum dz x) slabs
+    (conv(..., gnb=(x, aff)): adm_conv_args.prologue == 3) -- `dy` is then that dz and the partial pass is skipped."""
     n, h, w, c = x.shape
     hw = h * w
     lib = _L(x)
-    slabs = max(1, hw // GN_BWD_SLAB_PIXELS)
-    partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x.device)
     k1 = torch.empty((n, c), dtype=torch.float32, device=x.device)
     k0 = torch.empty((n, c), dtype=torch.float32, device=x.device)
     a, b = aff
-    check(lib.adm_gn_bwd_partial(_ptr(x, x.dtype, "x"), _ptr(dy, x.dtype, "dy"), _ptr(a, torch.float32), _ptr(b, torch.float32),
-                                 _ptr(partial), n, h, w, c, slabs, int(silu), int(dy_half), _stream()),
-          "adm_gn_bwd_partial")
+    if partial is None:
+        slabs = max(1, hw // GN_BWD_SLAB_PIXELS)
+        partial = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x.device)
+        check(lib.adm_gn_bwd_partial(_ptr(x, x.dtype, "x"), _ptr(dy, x.dtype, "dy"), _ptr(a, torch.float32), _ptr(b, torch.float32),
+                                     _ptr(partial), n, h, w, c, slabs, int(silu), int(dy_half), _stream()),
+              "adm_gn_bwd_partial")
+    else:
+        if dy_half or tuple(partial.shape[0:1] + partial.shape[2:]) != (n, c, 2):
+            raise AdmError("gn_bwd(partial=...): same-resolution dz and [n, slabs, c, 2] sums expected")
+        slabs = partial.shape[1]
+        silu = False   # the SiLU derivative is already in dz
     check(lib.adm_gn_bwd_finalize(_ptr(partial), _ptr(a), _ptr(stats, torch.float32, "stats"), _ptr(k1), _ptr(k0),
                                   n, c, hw, slabs, _stream()), "adm_gn_bwd_finalize")
     out = torch.empty_like(x)
-    check(lib.adm_gn_bwd_apply(_ptr(x), _ptr(dy), _ptr(a), _ptr(b), _ptr(k1), _ptr(k0), _ptr(add, x.dtype, "add"),
+    check(lib.adm_gn_bwd_apply(_ptr(x), _ptr(dy, x.dtype, "dy"), _ptr(a), _ptr(b), _ptr(k1), _ptr(k0), _ptr(add, x.dtype, "add"),
                                _ptr(out), n, h, w, c, int(silu), int(dy_half), int(add_half), _stream()),
           "adm_gn_bwd_apply")
     return out

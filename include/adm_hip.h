@@ -146,7 +146,9 @@ typedef struct adm_conv_args {
   const adm_bf16* res; void* out;
   int32_t n, h, w, c0, c1, cout;
   int32_t taps;      /* 9 or 1 */
-  int32_t prologue;  /* 0,1,2  */
+  int32_t prologue;  /* 0 raw, 1 affine, 2 affine + SiLU; 3 = raw input + GroupNorm-backward EPILOGUE (backward-data convs): with res = x
+                        (the GroupNorm input in front, same shape as out; not added) and aff_a / aff_b its affine,
+                        out = acc * SiLU'(a x + b) and out_stats = (sum out, sum out * x): adm_gn_bwd_partial is then not needed */
   int32_t out_mode;  /* 0,1    */
   int32_t variant;   /* tiling variant: 0 = auto (5 or 6 by least Cout padding, 3 for cout <= 16); 5 = 192-wide and
                         6 = 128-wide 8-wave tiles; 3 = 16-wide (output head / stem backward); 7 = 32x32x16 MFMA kernel;

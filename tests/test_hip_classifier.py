@@ -205,3 +205,36 @@ def test_reference_cond_fn_closure_runs_unchanged_over_the_hip_classifier(ops):
     assert x_in.grad is not None and torch.isfinite(x_in.grad).all()
     # without requires_grad the plain inference path is taken and no graph is recorded
     assert not m(x, t).requires_grad
+
+
+@pytest.mark.parametrize("n,hw,cin,cout", [(3, 16, 128, 128), (2, 32, 256, 128), (2, 16, 192, 384)])
+def test_gn_backward_sums_in_the_backward_conv_epilogue(n, hw, cin, cout):
+    """adm_conv prologue 3: the backward-data conv writes dz = conv(dy) * SiLU'(a x + b) and the (sum dz, sum dz x) slabs, so
+    GroupNorm backward is finalize + apply without the partial pass -- against the unfused chain and a PyTorch-CPU statement."""
+    import torch.nn.functional as F
+    from autodiffusion_amd import ops
+    g = torch.Generator().manual_seed(n * 1000 + hw)
+    x = torch.randn(n, cout, hw, hw, generator=g)
+    dy = torch.randn(n, cin, hw, hw, generator=g) * 0.5
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.2 * torch.randn(cout, generator=g)
+    bf = lambda t: t.to(torch.bfloat16).float()   # noqa: E731
+    xd = bf(x).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    dyd = bf(dy).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    zb = torch.zeros(max(cin, cout), device=DEV)
+    a, b, st = ops.gn_affine(xd, gamma.to(DEV), beta.to(DEV), want_stats=True)
+    plain = ops.conv(dyd, wp, zb, cout, 9)
+    want = ops.gn_bwd(xd, plain, (a, b), st, silu=True, add=xd)
+    dz = ops.conv(dyd, wp, zb, cout, 9, gnb=(xd, (a, b)))
+    got = ops.gn_bwd(xd, dz, (a, b), st, silu=True, add=xd, partial=dz._adm_stats[0])
+    rel = ((got.float() - want.float()).norm() / want.float().norm()).item()
+    assert rel <= 6e-3, rel
+    # the PyTorch statement: d/dx of sum(conv_out * SiLU(GroupNorm(x))) ... = autograd through GN + SiLU with upstream conv(dy)
+    xr = bf(x).requires_grad_(True)
+    up = F.conv2d(bf(dy), bf(w), padding=1)
+    y = F.silu(F.group_norm(xr, 32, gamma, beta, eps=1e-5))
+    (ref,) = torch.autograd.grad((y * up).sum(), xr)
+    ref = ref + bf(x)
+    r2 = ((got.float().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item()
+    assert r2 <= 1.5e-2, r2
