@@ -452,3 +452,26 @@ def test_conv_split_k_matches_the_one_pass_conv(ops, n, hw, c0, c1, cout, ks, pr
         ops.USE_FUSED_STATS = True
     torch.testing.assert_close(a1, a2, rtol=2e-5, atol=1e-6)
     torch.testing.assert_close(b1, b2, rtol=2e-4, atol=2e-5)
+
+
+def test_up_phase_and_gn_backward_epilogue_reject_unsupported_shapes(ops):
+    """The two late-round conv modes fail loudly (AdmError with the library's message) outside their domain; the callers
+    (ops.conv / classifier backward) route such shapes to the general paths instead."""
+    from autodiffusion_amd._lib import AdmError
+    x8 = torch.zeros(2, 8, 8, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(64, 64, 3, 3, device=DEV)
+    b = torch.zeros(64, device=DEV)
+    aff = (torch.ones(2, 64, device=DEV), torch.zeros(2, 64, device=DEV))
+    with pytest.raises(AdmError, match="fused statistics|prologue 3"):
+        ops.conv(x8, ops.pack_conv_weight(w), b, 64, 9, gnb=(x8, aff))          # 8x8 map: no 256-pixel tiles
+    with pytest.raises(AdmError, match="gnb"):
+        ops.conv(x8, ops.pack_conv_weight(w), b, 64, 9, gnb=(x8, aff), res=x8)  # the residual slot carries x
+    # an 8x8 source keeps the one-launch virtual upsample even when phase weights are offered
+    out = ops.conv(x8, ops.pack_conv_weight(w), b, 64, 9, in_up=True, w_up=ops.pack_conv_weight_up(w))
+    assert out.shape == (2, 16, 16, 64)
+    a = ops.ConvArgs()
+    a.in0, a.w_packed, a.bias, a.out = x8.data_ptr(), ops.pack_conv_weight(w).data_ptr(), b.data_ptr(), out.data_ptr()
+    a.n, a.h, a.w, a.c0, a.cout, a.taps, a.up_phase = 2, 8, 8, 64, 64, 9, 2
+    from autodiffusion_amd import _lib
+    rc = _lib.load().adm_conv(__import__("ctypes").byref(a), None)
+    assert rc == -2 and b"up_phase" in _lib.load().adm_last_error()
