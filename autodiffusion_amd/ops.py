@@ -229,24 +229,29 @@ FUSE_GN_BWD = os.environ.get("ADM_FUSE_GN_BWD", "1") != "0"   # GroupNorm-backwa
 UPCONV_PHASES = os.environ.get("ADM_UPCONV_PHASES", "1") != "0"   # conv3x3(upsample2x(x)) as four 2x2-tap phase convs (4/9 of the MACs)
 
 
-def pack_conv_weight_up(w, dtype=BF16):
-    """The four phase weights of conv3x3(nearest-upsample-2x(x), w) (adm_conv_args.up_phase): for output pixels
-    (2y + py, 2x + px) the nine taps collapse onto a 2x2 window of the half-resolution source -- rows {y-1, y} carry
-    {w0, w1 + w2} for py = 0 and rows {y, y+1} carry {w0 + w1, w2} for py = 1, likewise for columns -- summed in fp32 and
-    embedded in a 3x3 window around (y, x) (5 zero taps, skipped by the kernel).  Returns a [4, elems] packed tensor."""
+def up_phase_weights(w):
+    """fp32 [4, cout, cin, 3, 3]: for phase ph = 2 py + px the weights of the 3x3 conv on the HALF-resolution source x that gives
+    the output pixels (2y + py, 2x + px) of conv3x3(nearest-upsample-2x(x), w).  The nine taps collapse onto a 2x2 window: window
+    rows {y-1, y, y+1} carry {w0, w1 + w2, 0} for py = 0 and {0, w0 + w1, w2} for py = 1, likewise for columns (5 zero taps).
+    Pure tensor algebra (testable without a GPU)."""
     w32 = w.detach().to(torch.float32)
     rows = {0: [[0], [1, 2], []], 1: [[], [0, 1], [2]]}   # window row r <- original taps, by phase
-    packed = []
+    out = torch.zeros((4,) + tuple(w32.shape), dtype=torch.float32, device=w32.device)
     for ph in range(4):
         py, px = ph >> 1, ph & 1
-        wp = torch.zeros_like(w32)
         for r in range(3):
             for c in range(3):
                 for ky in rows[py][r]:
                     for kx in rows[px][c]:
-                        wp[:, :, r, c] += w32[:, :, ky, kx]
-        packed.append(pack_conv_weight(wp, dtype))
-    return torch.stack(packed, 0).contiguous()
+                        out[ph, :, :, r, c] += w32[:, :, ky, kx]
+    return out
+
+
+def pack_conv_weight_up(w, dtype=BF16):
+    """The four phase weights of conv3x3(nearest-upsample-2x(x), w) (adm_conv_args.up_phase; up_phase_weights), summed in fp32
+    and packed like any 3x3 weight: a [4, elems] tensor."""
+    wp = up_phase_weights(w)
+    return torch.stack([pack_conv_weight(wp[ph], dtype) for ph in range(4)], 0).contiguous()
 
 
 def pack_conv_weight32(w, dtype=BF16):

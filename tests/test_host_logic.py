@@ -146,3 +146,21 @@ def test_asking_for_the_fp32_network_warns_loudly(monkeypatch):
         d["use_fp16"] = True
         create_model_and_diffusion(**d)
     assert not w
+
+
+def test_upsample_conv_equals_four_phase_convs_on_the_half_resolution_source():
+    """The algebra behind adm_conv_args.up_phase (ops.up_phase_weights): conv3x3(nearest-upsample-2x(x), w) restricted to the
+    output pixels (2y + py, 2x + px) is a 3x3 conv of x itself with pre-summed weights of which 5 taps are zero (4/9 of the MACs)."""
+    import torch
+    import torch.nn.functional as F
+    from autodiffusion_amd.ops import up_phase_weights
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 5, 6, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64)
+    full = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    wp = up_phase_weights(w).to(torch.float64)
+    for ph in range(4):
+        py, px = ph >> 1, ph & 1
+        torch.testing.assert_close(F.conv2d(x, wp[ph], padding=1), full[:, :, py::2, px::2], rtol=1e-5, atol=1e-5)
+        live = (wp[ph].abs().sum((0, 1)) > 0)
+        assert int(live.sum()) == 4 and bool(live[py:py + 2, px:px + 2].all())      # the 2x2 window the kernel's tap mask names
