@@ -80,6 +80,10 @@ struct ConvK {
   // the others skip their fragment reads and MFMAs --, the output is written with pixel stride 2 at offset (ooy, oox)
   // into the [N][2H][2W][Cout] tensor, and the fused statistics go to slab (tile * 4 + slab_off) of 4 x as many slabs
   int tap_mask, ooy, oox, slab_off;
+  // up_phase == 5: all four phases in ONE launch -- the Cout-block index of a tile runs over nph * nbp values, phase = nb / nbp,
+  // and phase p's packed weights start phase_bytes * p into `w` (the tile list is 4 x as long: small batches still fill the CUs)
+  int nph, nbp;
+  unsigned phase_bytes;
 };
 
 // output-statistics slabs per tile: a 128-pixel tile is two 8x8 images (or two halves of one image)
@@ -232,6 +236,7 @@ conv_kernel(const ConvK p) {
 
   // ---- per-tile state (rewritten at every tile switch)
   int nb = 0, mt = 0, img0 = 0, y0 = 0, x0 = 0;
+  [[maybe_unused]] int ph = p.slab_off;   // up-conv phase of the current tile (fixed per launch unless p.nph == 4)
   int sp = 0, cb = 0, ce = chunks;   // K split of the tile: chunks [cb, ce)
   __amdgpu_buffer_rsrc_t rs0 = rsw, rs1 = rsw;
   int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch / spare slot)
@@ -249,6 +254,9 @@ conv_kernel(const ConvK p) {
     }
     nb_ = lt % p.nblocks_n;
     mt_ = lt / p.nblocks_n;
+    if constexpr (UPPH) {
+      if (p.nph > 1) { ph = nb_ / p.nbp; nb_ -= ph * p.nbp; }
+    }
     if (p.TI == 1) {
       const int per_img = p.tiles_x * p.tiles_y;
       img0_ = mt_ / per_img;
@@ -314,7 +322,7 @@ conv_kernel(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int tile = nb * (BN / 16) + wn * TN + j;
-      wofs[j] = tile < p.ntiles16 ? (unsigned)((tile * 64 + lane) * 16) : OOB;
+      wofs[j] = tile < p.ntiles16 ? (unsigned)((tile * 64 + lane) * 16) + (UPPH ? (unsigned)ph * p.phase_bytes : 0u) : OOB;
     }
   };
 
@@ -506,7 +514,7 @@ conv_kernel(const ConvK p) {
             if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
           }
           hprev = hcur;
-          if (!UPPH || ((p.tap_mask >> t) & 1))   // up-conv phase: 5 of the 9 taps carry zero weights (wave-uniform skip)
+          if (!UPPH || (((0x1b << ((ph >> 1) * 3 + (ph & 1))) >> t) & 1))   // up-conv phase: 5 of the 9 taps carry zero weights (wave-uniform skip)
             mfma_tap(halo + hb * Lds::HB + ((t / 3) * HW2 + (t % 3)) * ROWB, wr[t % 3]);
         }
         __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
@@ -620,7 +628,7 @@ conv_kernel(const ConvK p) {
       // (a) this tile's output / residual bases and statistics destinations (the per-row offsets follow the
       // tile switch: they only need the first image of the finished tile)
       // element offset of the tile origin (up-conv phase: output map 2H x 2W, this phase's pixels at stride 2)
-      const long long ebase = UPPH ? (((long long)img0 * (2 * p.H) + 2 * y0 + p.ooy) * (2 * p.W) + 2 * x0 + p.oox) * p.Cout + gch
+      const long long ebase = UPPH ? (((long long)img0 * (2 * p.H) + 2 * y0 + (ph >> 1)) * (2 * p.W) + 2 * x0 + (ph & 1)) * p.Cout + gch
                                    : (((long long)img0 * p.H + y0) * p.W + x0) * p.Cout + gch;
       uint16_t* const obase = reinterpret_cast<uint16_t*>(p.out) + ebase;
       // residual through a virtual 2x upsample: source map (H/2) x (W/2); tile origins are even
@@ -632,7 +640,7 @@ conv_kernel(const ConvK p) {
       for (int g = 0; g < SGROUPS; ++g) {
         const int n = img0 + ((g * RG) >> p.thw_shift);
         // slab of this group inside its image: (tile of the image) * SGROUPS + g for one-image tiles
-        const int slab = p.TI == 1 ? (UPPH ? (mt % (p.tiles_x * p.tiles_y)) * 4 + p.slab_off : (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g) : 0;
+        const int slab = p.TI == 1 ? (UPPH ? (mt % (p.tiles_x * p.tiles_y)) * 4 + ph : (mt % (p.tiles_x * p.tiles_y)) * SGROUPS + g) : 0;
         sdst[g] = (p.stats && tid_e < BN && nb * BN + tid_e < p.Cout && n < p.N)
                       ? p.stats + (((long long)n * p.stat_slabs + slab) * p.Cout + nb * BN + tid_e) * 2 : nullptr;
       }
@@ -1209,7 +1217,8 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
     slots = per_cu * ncu;
   }
   ConvK kk = k;
-  kk.nblocks_n = (k.Cout + BN - 1) / BN;
+  kk.nbp = (k.Cout + BN - 1) / BN;
+  kk.nblocks_n = kk.nbp * (k.nph > 1 ? k.nph : 1);
   const long long tiles = (long long)m_tiles * kk.nblocks_n * (k.ksplit > 1 ? k.ksplit : 1);
   ADM_REQUIRE(tiles < (1ll << 31), ADM_E_SHAPE, "adm_conv: too many tiles");
   kk.total_tiles = (int)tiles;
@@ -1406,15 +1415,14 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   if (a->up_phase) {
     // phase (py, px) = up_phase - 1: out[2y + py][2x + px] = sum over the source window rows {y - 1 + py, y + py} x columns
     // {x - 1 + px, x + px}: taps (ky, kx) in {py, py + 1} x {px, px + 1} of the 3x3 window around source pixel (y, x)
-    ADM_REQUIRE(a->up_phase >= 1 && a->up_phase <= 4, ADM_E_ARG, "adm_conv: up_phase must be 0 or 1..4");
+    ADM_REQUIRE(a->up_phase >= 1 && a->up_phase <= 5, ADM_E_ARG, "adm_conv: up_phase must be 0, 1..4 (one phase) or 5 (all four)");
     ADM_REQUIRE(a->taps == 9 && a->out_mode == 0 && a->c1 == 0 && !a->res && !a->in_up && !a->res_up && a->ksplit <= 1 &&
                 a->h >= 16 && a->w >= 16, ADM_E_SHAPE,
                 "adm_conv: up_phase needs a 3x3 conv with bf16 output, one source >= 16x16, no residual / split-K / in_up");
     const int py = (a->up_phase - 1) >> 1, px = (a->up_phase - 1) & 1;
-    k.tap_mask = 0;
-    for (int ky = py; ky <= py + 1; ++ky)
-      for (int kx = px; kx <= px + 1; ++kx) k.tap_mask |= 1 << (ky * 3 + kx);
-    k.ooy = py; k.oox = px; k.slab_off = a->up_phase - 1;
+    k.tap_mask = 0x1b << (py * 3 + px);   // taps (ky, kx) in {py, py + 1} x {px, px + 1}; != 0x1ff selects the TAPS = 4 instantiation
+    k.ooy = py; k.oox = px; k.slab_off = a->up_phase == 5 ? 0 : a->up_phase - 1;
+    k.nph = a->up_phase == 5 ? 4 : 1;
   }
   k.ksplit = a->ksplit > 1 ? a->ksplit : 1;
   k.cps = 0;
@@ -1430,6 +1438,11 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   }
   k.ntiles16 = (a->cout + 15) / 16;
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
+  if (a->up_phase == 5) {   // four packed weights back to back
+    ADM_REQUIRE((long long)k.wbytes * 4 < (1ll << 31), ADM_E_SHAPE, "adm_conv: up_phase 5: weights beyond 2 GiB");
+    k.phase_bytes = k.wbytes;
+    k.wbytes *= 4;
+  }
   hipStream_t s = (hipStream_t)stream;
 
   const int variant = pick_variant(a);

@@ -365,8 +365,8 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
 
 
 def _conv_up_phases(x0, w_up, bias, cout, aff, silu, out, want_stats):
-    """conv3x3(upsample2x(x0)) as four adm_conv launches with up_phase = 1..4 (include/adm_hip.h): x0 is the
-    half-resolution source [n, h, w, c0], the result [n, 2h, 2w, cout]."""
+    """conv3x3(upsample2x(x0)) as the four 2x2-tap phase convs of adm_conv_args.up_phase, all in one launch (up_phase = 5):
+    x0 is the half-resolution source [n, h, w, c0], the result [n, 2h, 2w, cout]."""
     n, h, w, c0 = x0.shape
     dev = x0.device
     lib = _L(x0)
@@ -379,8 +379,10 @@ def _conv_up_phases(x0, w_up, bias, cout, aff, silu, out, want_stats):
         a.prologue = 2 if silu else 1
     a.out = _ptr(out)
     a.n, a.h, a.w, a.c0, a.c1, a.cout = n, h, w, c0, 0, cout
-    a.taps, a.out_mode, a.up_phase = 9, 0, 1
-    a.w_packed = _ptr(w_up[0], x0.dtype, "w_up")
+    a.taps, a.out_mode, a.up_phase = 9, 0, 5   # 5: the four phases in one launch (phase = part of the tile index)
+    if not w_up.is_contiguous() or w_up.dim() != 2 or w_up.shape[0] != 4:
+        raise AdmError("conv(w_up=...): the [4, elems] tensor of pack_conv_weight_up expected")
+    a.w_packed = _ptr(w_up, x0.dtype, "w_up")
     variant = a.variant = lib.adm_conv_pick_variant(C.byref(a))
     if want_stats and USE_FUSED_STATS:
         slabs = lib.adm_conv_stat_slabs(C.byref(a))
@@ -392,10 +394,7 @@ def _conv_up_phases(x0, w_up, bias, cout, aff, silu, out, want_stats):
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    for ph in range(4):
-        a.up_phase = ph + 1
-        a.w_packed = _ptr(w_up[ph], x0.dtype, "w_up")
-        check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
+    check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
     if prof:
         e1.record()
         # algorithmic work of the layer as the reference states it: a 9-tap conv on the upsampled map

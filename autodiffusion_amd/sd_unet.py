@@ -228,8 +228,8 @@ class UNetModel(HipModule):
                 else:              # stride-1 conv + every-second-pixel pick: 4 x the MACs on the faster tile kernel
                     h = ops.resample(ops.conv(h, d["w"], d["b"], blk.channels, 9), "stride2")
             elif isinstance(blk, SDUpSpec):
-                # four 2x2-tap phase launches pay off once a launch has a few hundred tiles (batch >= ~48 latents); at the
-                # search's 6-latent half batches the one-launch virtual upsample is 1.4-2.5 x faster (tools/upconv_bench.py)
+                # the four 2x2-tap phase convs of the upsample in one launch (adm_conv_args.up_phase = 5): 4/9 of the MACs,
+                # x 1.2-1.3 on these layers at the search's 6-latent half batches (tools/upconv_bench.py)
                 h = ops.conv(h, d["w"], d["b"], blk.channels, 9, in_up=True, want_stats=True,
                              w_up=d["w_up"] if self.upconv_phases else None)
             else:
@@ -241,7 +241,7 @@ class UNetModel(HipModule):
     use_graph = False  # replay one captured hipGraph per input shape (set by .enable_graph())
 
     small_batch_splitk = False  # split the K loop of the 8x8 / 16x16-level 3x3 convs (set by .enable_splitk())
-    upconv_phases = False       # Upsample convs as four 2x2-tap phase launches (large batches only; .enable_upconv_phases())
+    upconv_phases = ops.UPCONV_PHASES   # Upsample convs as four 2x2-tap phase convs (a per-model choice, never by batch)
 
     def enable_upconv_phases(self, on: bool = True):
         self.upconv_phases = bool(on)

@@ -173,9 +173,10 @@ typedef struct adm_conv_args {
                         the pixels (2y + py, 2x + px).  Each phase is a 2x2-tap conv of the source: w_packed holds its pre-summed
                         weights embedded in a 3x3 window (adm_pack_conv_weight of the host-made 3x3 tensor: rows {w0, w1 + w2, 0}
                         for py = 0, {0, w0 + w1, w2} for py = 1, likewise for columns); the 5 zero taps are skipped: 4/9 of the
-                        MACs of in_up = 1.  Four launches (one per phase) replace one in_up conv; out_stats then has
-                        adm_conv_stat_slabs = 4 x (h / 16) x (w / 16) slabs, each launch filling its quarter.  3x3, bf16 output,
-                        c1 == 0, no residual, source >= 16x16, variant 0/5/6                                                    */
+                        MACs of in_up = 1.  up_phase = 5 runs all four phases in ONE launch: w_packed then holds the four packed weights
+                        back to back (phase-major) and the phase is part of the tile index (4 x as many tiles: small batches
+                        still fill the chip).  out_stats has adm_conv_stat_slabs = 4 x (h / 16) x (w / 16) slabs, one per
+                        (source tile, phase).  3x3, bf16 output, c1 == 0, no residual, source >= 16x16, variant 0/5/6            */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

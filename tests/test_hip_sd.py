@@ -146,11 +146,13 @@ def test_sd_unet_matches_reference_golden(name):
         assert not torch.equal(want2, out)
         assert torch.equal(m(x, t, ctx2, context_key="b"), want2) and torch.equal(m(x, t, ctx, context_key="c"), out)
     m.enable_graph(False)
-    # Upsample convs as four 2x2-tap phase launches (large-batch option): the same network up to the rounding of the pre-summed taps
-    ph = m.enable_upconv_phases()(x, t, ctx)
-    m.enable_upconv_phases(False)
-    check(ph, g["out"], name + " (up-conv phases)")
-    assert not torch.equal(ph, out) or x.shape[-1] < 32      # (maps below 16x16 keep the one-launch path)
+    # Upsample convs as one 9-tap launch instead of the four 2x2-tap phase convs (the default): the same network up to the rounding
+    # of the pre-summed taps
+    assert m.upconv_phases
+    one = m.enable_upconv_phases(False)(x, t, ctx)
+    m.enable_upconv_phases(True)
+    check(one, g["out"], name + " (one-launch upsample convs)")
+    assert not torch.equal(one, out) or x.shape[-1] < 32      # (maps below 16x16 keep the one-launch path either way)
     if name == "sd_unet_tiny":  # ragged batch reproduces per-image results
         out3 = m(torch.cat([x, x[:1]]), torch.cat([t, t[:1]]), torch.cat([ctx, ctx[:1]]))
         assert torch.equal(out3[:2], out) and torch.equal(out3[2], out[0])
