@@ -99,7 +99,10 @@ linear_kernel(const float* __restrict__ in, const float* __restrict__ w, const f
 // 50 TFLOP/s on that shape (264 us average, 1.2 % of the guided batch, profiles/r02/bench_guided_b256_b_kernel_stats.csv).
 typedef __attribute__((ext_vector_type(4))) float lin_f32x4;
 
-template <bool SILU, int KU>   // KU float4 per operand row and step: 16 * KU k-values per step (k % (16 * KU) == 0)
+// COLSPLIT (n <= 64 rows: one 64-row wave tile holds them all): the four waves of a block take four 32-column groups instead
+// of four 64-row groups, so that no wave idles.  An output element sees the same MFMA sequence either way: a row's bits do not
+// depend on the batch it rides in (the kernel is chosen by (k, alignment) only -- adm_linear_f32).
+template <bool SILU, int KU, bool COLSPLIT>   // KU float4 per operand row and step: 16 * KU k-values per step (k % (16 * KU) == 0)
 __global__ void __launch_bounds__(256)
 linear_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                    const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ out,
@@ -107,8 +110,9 @@ linear_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w, co
   constexpr int TM = 4, TN = 2, KSTEP = 16 * KU;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lc = lane & 15, lq = lane >> 4;
-  const int row0 = (blockIdx.y * 4 + wave) * (TM * 16), col0 = blockIdx.x * (TN * 16);
-  if (row0 >= n) return;   // wave-uniform; no barriers in this kernel
+  const int row0 = COLSPLIT ? 0 : (blockIdx.y * 4 + wave) * (TM * 16);
+  const int col0 = (COLSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * (TN * 16);
+  if (row0 >= n || col0 >= o) return;   // wave-uniform; no barriers in this kernel
   const float* ap[TM];
   const float* bp[TN];
 #pragma unroll
@@ -269,9 +273,24 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
   hipStream_t s = (hipStream_t)stream;
   const size_t small_lds = (size_t)LS_ROWS * k * sizeof(float);
   const bool mfma_ok = k % 16 == 0 && adm_aligned16(w) && adm_aligned16(in);
-  // few rows: the GEMV-shaped kernel (below 32 rows a 64-row MFMA tile is mostly empty; at 64 rows x 1024 -> 40 960
-  // -- the LSUN-256 model's emb_layers at batch 64 -- it took 421 us against ~100 on the matrix pipe)
-  if (n <= 64 && !(mfma_ok && n >= 32) && k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
+  // The kernel is chosen by (k, alignment) alone, never by the number of rows: the kernels sum k in different orders, and a
+  // row's embedding bits must not depend on the batch it rides in (an image's result is independent of how a candidate's
+  // images are sharded and batched: tests/test_hip_bigbatch.py holds the whole UNet to that, bitwise, at batch 256 vs 2).
+  if (mfma_ok) {
+    // 16 k-values per step: 32- and 64-deep steps (KU = 2, 4) measured 15 % slower (205 vs 179 us on 256 x 768 -> 33 792)
+    if (n <= 64) {   // one wave tile of rows: the block's four waves split the columns
+      dim3 g((o + 127) / 128, 1);
+      if (silu_in) hipLaunchKernelGGL((linear_mfma_kernel<true, 1, true>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+      else hipLaunchKernelGGL((linear_mfma_kernel<false, 1, true>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+    } else {
+      dim3 g((o + 31) / 32, (n + 255) / 256);
+      if (silu_in) hipLaunchKernelGGL((linear_mfma_kernel<true, 1, false>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+      else hipLaunchKernelGGL((linear_mfma_kernel<false, 1, false>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
+    }
+    return adm_check_launch("adm_linear_f32");
+  }
+  // k not a multiple of 16 (or unaligned operands), few rows: the GEMV-shaped kernel
+  if (n <= 64 && k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
     static bool attr_set[64][2] = {};  // per device: opt in to the dynamic LDS size once per instantiation
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -286,13 +305,6 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
     dim3 g((o + 4 * LS_CPW - 1) / (4 * LS_CPW), (n + LS_ROWS - 1) / LS_ROWS);
     if (silu_in) hipLaunchKernelGGL((linear_small_kernel<true>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
     else hipLaunchKernelGGL((linear_small_kernel<false>), g, dim3(256), small_lds, s, in, w, bias, table, idx, out, n, k, o);
-    return adm_check_launch("adm_linear_f32");
-  }
-  if (mfma_ok) {
-    dim3 g((o + 31) / 32, (n + 255) / 256);
-    // 16 k-values per step: 32- and 64-deep steps (KU = 2, 4) measured 15 % slower (205 vs 179 us on 256 x 768 -> 33 792)
-    if (silu_in) hipLaunchKernelGGL((linear_mfma_kernel<true, 1>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
-    else hipLaunchKernelGGL((linear_mfma_kernel<false, 1>), g, dim3(256), 0, s, in, w, bias, table, idx, out, n, k, o);
     return adm_check_launch("adm_linear_f32");
   }
   dim3 grid((o + LT - 1) / LT, (n + LT - 1) / LT);

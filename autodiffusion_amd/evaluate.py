@@ -50,6 +50,8 @@ class CandidateEvaluator:
             self.skip_layers = None
             steps = cand
         apply_candidate(self.active_diffusion, self.base_diffusion, steps)
+        if hasattr(self.model, "plan_graphs"):   # one captured launch sequence per distinct skip set of this candidate
+            self.model.plan_graphs(len({tuple(sorted(s)) for s in self.skip_layers}) if self.skip_layers is not None else 1)
         return self
 
     # closures with the reference's calling convention ------------------------------------------

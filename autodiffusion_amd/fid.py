@@ -98,8 +98,14 @@ class ActivationAccumulator:
         """add(features(u8)) on a SIDE stream, behind everything queued so far on the current stream: the extractor's launches
         (small grids on the 8x8 / 17x17 levels at sampling batch sizes) then fill CUs next to the next batch's sampling
         kernels instead of running between two batches.  Same launches in the same order on one stream: bitwise the sums of
-        add(); every reader of the sums joins first."""
-        if not (self.OVERLAP and u8.is_cuda):
+        add(); every reader of the sums joins first.
+
+        Stream contract of `features`: the side stream is only used for an extractor that declares `stream_safe = True`,
+        i.e. that enqueues ALL its work on torch's CURRENT stream (the bundled HIP Inception-v3 does: inception.pool3_features).
+        A plug-in that launches on the null stream or on a stream of its own would no longer be ordered with the
+        accumulation kernel queued behind it here (a silent read-before-write of `acts`), so any other callable runs on the
+        caller's stream, in order, as add(features(u8)) does."""
+        if not (self.OVERLAP and u8.is_cuda and getattr(features, "stream_safe", False)):
             self.add(features(u8))
             return
         if self._side is None:

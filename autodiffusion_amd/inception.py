@@ -329,10 +329,20 @@ class Evaluator_v1:
         return np.concatenate(preds, axis=0), np.zeros((batches.shape[0], 0), dtype=np.float32)
 
 
-def pool3_features(device, weights_path: str = "", mode: str = "tf1", dtype: torch.dtype = torch.float16):
+InceptionV3.features.stream_safe = True   # every launch goes to torch's current stream (fid.ActivationAccumulator.add_from)
+
+
+def pool3_features(device, weights_path: str = "", mode: str = "tf1", dtype: torch.dtype = torch.float16,
+                   allow_random: bool = False):
     """``--features`` factory of scripts/search_ea.py: -> (features(uint8 NHWC device batch) -> fp32 [B, 2048], 2048).
     weights_path: a state_dict file in the pt_inception-2015-12-05 / torchvision / pytorch_fid key layout (.pth read with
-    torch.load(weights_only=True), or .safetensors); empty = random weights (a loud warning: FID values are meaningless)."""
+    torch.load(weights_only=True), or .safetensors).  Without it the extractor would score candidates on RANDOM weights --
+    a meaningless metric that looks like a result in log.txt -- so that needs an explicit allow_random=True (benchmarks,
+    tests); the returned callable then carries `random_weights = True` and the searchers tag every FID line they log.
+    `features.stream_safe = True`: every launch goes to torch's current stream (fid.ActivationAccumulator.add_from)."""
+    if not weights_path and not allow_random:
+        raise ValueError("pool3_features: no Inception-v3 checkpoint given (--inception_path): FID values on random weights are "
+                         "meaningless; pass allow_random=True (--inception_random True) for throughput runs and tests")
     m = InceptionV3(dtype=dtype).to(device)
     if weights_path:
         if weights_path.endswith(".safetensors"):
@@ -341,4 +351,12 @@ def pool3_features(device, weights_path: str = "", mode: str = "tf1", dtype: tor
         else:
             sd = torch.load(weights_path, map_location="cpu", weights_only=True)
         m.load_state_dict(sd)
-    return (lambda u8: m.features(u8, mode)), 2048
+    if not weights_path:
+        m.weights_loaded = True   # asked for: the searchers' per-line tag replaces the first-use warning
+
+    def features(u8):
+        return m.features(u8, mode)
+    features.random_weights = not weights_path
+    features.stream_safe = True
+    features.net = m
+    return features, 2048

@@ -326,8 +326,9 @@ class UNetModel(HipModule):
         # static buffers (the memory fault recorded in round 1 when two half-batches were replayed concurrently).  With
         # the stream in the key, evaluations on different streams own disjoint graphs and may overlap; replays on one
         # stream serialise by stream order.
+        # the launch-sequence switches are part of the key: toggling one after the first replay must not keep the old capture
         key = (tuple(x.shape), x.dtype, tuple(timesteps.shape), timesteps.dtype, tuple(context.shape),
-               torch.cuda.current_stream(x.device).cuda_stream)
+               torch.cuda.current_stream(x.device).cuda_stream, self.small_batch_splitk, self.upconv_phases)
         entry = pr.graphs.get(key)
         if entry is None:
             sx, st = x.clone(), timesteps.clone()

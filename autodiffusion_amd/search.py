@@ -68,6 +68,11 @@ class EvolutionSearcher(object):
         self.features = features
         self.feature_dim = feature_dim
         self.ref_stats = ref_stats
+        # an extractor that runs on random weights (inception.pool3_features(allow_random=True): throughput runs, tests) ranks
+        # candidates on a meaningless metric: every FID line of log.txt says so, next to the value
+        self.fid_note = (" [FID on RANDOM Inception weights: not a quality metric]"
+                         if getattr(features, "random_weights", False) else "")
+        self.last_times = None   # {'reset_time', 'sample_time', 'fid_time', 'images'} of the last get_cand_fid
         if ref_stats is None and getattr(args, "ref_path", ""):
             # the reference pickles a FIDStatistics; this build reads the two arrays from an .npz
             # (mu, sigma) written from it -- unpickling foreign files is not done here
@@ -145,6 +150,8 @@ class EvolutionSearcher(object):
             fid = float(cal_fid(arr, 64, self.evaluator, ref_stats=self.ref_stats))
         fid_time = time.time() - t1
         logger.log('reset_time: ' + str(reset_time) + ', sample_time: ' + str(sample_time) + ', fid_time: ' + str(fid_time))
+        self.last_times = {"reset_time": reset_time, "sample_time": sample_time, "fid_time": fid_time,
+                           "images": int(args.num_samples), "batches_this_rank": batch_idx}
         return fid
 
     # ------------------------------------------------------------------ EA bookkeeping (reference order of RNG draws)
@@ -175,7 +182,7 @@ class EvolutionSearcher(object):
             self._pending.append(cand)  # evaluated by flush_pending(), sharded over ranks
         else:
             info['fid'] = self.get_cand_fid(args=self.args, cand=eval(cand))
-            logger.log('cand: {}, fid: {}'.format(cand, info['fid']))
+            logger.log('cand: {}, fid: {}'.format(cand, info['fid']) + self.fid_note)
         info['visited'] = True
         return True
 
@@ -224,7 +231,7 @@ class EvolutionSearcher(object):
                 fids[i] = float(parts[owner[i]][i])
         for cand, fid in zip(pending, fids):
             self.vis_dict[cand]['fid'] = float(fid)
-            logger.log('cand: {}, fid: {}'.format(cand, float(fid)))
+            logger.log('cand: {}, fid: {}'.format(cand, float(fid)) + self.fid_note)
 
     def is_legal_before_search(self, cand):
         return self._visit(cand)
@@ -339,7 +346,7 @@ class EvolutionSearcher(object):
             self.update_top_k(self.candidates, k=50, key=lambda x: self.vis_dict[x]['fid'])
             logger.log('epoch = {} : top {} result'.format(self.epoch, len(self.keep_top_k[50])))
             for i, cand in enumerate(self.keep_top_k[50]):
-                logger.log('No.{} {} fid = {}'.format(i + 1, cand, self.vis_dict[cand]['fid']))
+                logger.log('No.{} {} fid = {}'.format(i + 1, cand, self.vis_dict[cand]['fid']) + self.fid_note)
             if self.break_at_last_epoch and self.epoch + 1 == self.max_epochs:
                 break
             self.candidates = self.get_mutation(self.select_num, self.mutation_num, self.m_prob)
@@ -513,7 +520,7 @@ class DynamicEvolutionSearcher(EvolutionSearcher):
             self.update_top_k(self.candidates, k=50, key=lambda x: self.vis_dict[x]['fid'])
             logger.log('epoch = {} : top {} result'.format(self.epoch, len(self.keep_top_k[50])))
             for i, cand in enumerate(self.keep_top_k[50]):
-                logger.log('No.{} {} fid = {}'.format(i + 1, cand, self.vis_dict[cand]['fid']))
+                logger.log('No.{} {} fid = {}'.format(i + 1, cand, self.vis_dict[cand]['fid']) + self.fid_note)
             best = self.keep_top_k[50][0]
             if self.skip_layer_range[1] == 0 and (self.last_best_cand == best or self.epoch > 4):
                 self.skip_layer_range[1] = self.max_prun / 5

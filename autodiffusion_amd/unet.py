@@ -216,10 +216,28 @@ class AdmNet(HipModule):
     upconv_phases = ops.UPCONV_PHASES
 
     use_graph = False
-    GRAPH_CACHE = 12
+    GRAPH_CACHE = 12        # graphs kept per model (LRU); plan_graphs() raises it to the active candidate's needs
+    GRAPH_CACHE_MAX = 32    # ... up to this many (each graph owns a private activation pool)
+    _graph_eager = False    # the active candidate needs more graphs than GRAPH_CACHE_MAX: evaluate eagerly
 
     def enable_graph(self, flag: bool = True):
         self.use_graph = bool(flag)
+        return self
+
+    def plan_graphs(self, distinct_sets: int):
+        """Called per candidate (CandidateEvaluator.set_candidate) with the number of DISTINCT layer-skip sets its steps use:
+        each needs its own captured launch sequence.  An LRU smaller than that count would miss on every evaluation of every
+        batch (recapture = 2 warm-up runs + capture + sync: several times slower than eager), so the cache grows to the
+        candidate's needs up to GRAPH_CACHE_MAX; beyond that the candidate is evaluated eagerly, with one log line."""
+        from . import logger
+        if distinct_sets <= self.GRAPH_CACHE_MAX:
+            self.GRAPH_CACHE = max(type(self).GRAPH_CACHE, int(distinct_sets))
+            self._graph_eager = False
+        else:
+            if not self._graph_eager:
+                logger.log(f"hipGraph replay off for this candidate: {distinct_sets} distinct layer-skip sets > "
+                           f"{self.GRAPH_CACHE_MAX} cached graphs (eager launches instead of recapturing every step)")
+            self._graph_eager = True
         return self
 
     def _graphed(self, key, fn, inputs):
@@ -227,7 +245,10 @@ class AdmNet(HipModule):
         pr = self._packed
         graphs = pr.__dict__.setdefault("graphs", OrderedDict())
         dev = inputs[0].device
-        key = key + tuple((tuple(t.shape), t.dtype) for t in inputs) + (torch.cuda.current_stream(dev).cuda_stream,)
+        # ... and the per-model launch-sequence switches: toggling one after the first replay must not keep the old capture
+        key = key + tuple((tuple(t.shape), t.dtype) for t in inputs) + (torch.cuda.current_stream(dev).cuda_stream,
+                                                                       self.upconv_phases, getattr(self, "fuse_gn_bwd", None),
+                                                                       getattr(self, "fold_skip", None))
         entry = graphs.get(key)
         if entry is None:
             static_in = [t.clone() for t in inputs]
@@ -447,7 +468,7 @@ class UNetModel(AdmNet):
         if skip_layer and not self.plan.dynamic:
             raise TypeError("skip_layer needs a dynamic UNet (use_dynamic_unet=True)")
         x = x.to(torch.float32).contiguous()
-        if self.use_graph and ops.CONV_PROFILE is None and timesteps.is_cuda:
+        if self.use_graph and not self._graph_eager and ops.CONV_PROFILE is None and timesteps.is_cuda:
             ins = (x, timesteps.contiguous()) + (() if y is None else (y.contiguous(),))
             return self._graphed(("unet", tuple(sorted(skip_ids))),
                                  lambda x_, t_, y_=None: self._forward(pr, x_, t_, y_, skip_ids), ins)

@@ -6,10 +6,19 @@ DDIM schedule [153, 424, 926, 690] through the ADM-G ImageNet-64 UNet (classifie
 --workload guided), ending in the fused uint8 NHWC pack.  Synthetic data: x_T ~ N(0,1), labels
 ~ U{0..999}, random-init weights of the real architecture (no checkpoint is reachable offline).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload guided|unguided|adm256|sd]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload guided|unguided|adm128|adm256|sd|candidate]
 
 --workload adm256 = the 256x256 line of the north star: ADM LSUN-256 dynamic UNet (search_lsun_cat.sh:1; 552.8 M, 2242.9
-GFLOP per image and evaluation), unconditional, uniform 5-step DDIM (the search's `--time_step 5` start candidate).
+GFLOP per image and evaluation), unconditional, uniform 5-step DDIM (the search's `--time_step 5` start candidate);
+`--skip-layers auto|<json>` gives every step a layer-skip list and `--with-fid` adds the pooled-FID stage: BASELINE config 5.
+--workload adm128 = BASELINE config 3's per-GPU unit: ADM-G ImageNet-128 (configs/128_guided_sample.sh:1-3: 421.5 M UNet with
+128 / 192 / 256-wide attention heads + the 128x128 depth-2 classifier), classifier-guided, a 10-step candidate, batch 32.
+--workload candidate = ONE WHOLE get_cand_fid per step at the reference's own search flags
+(search_imagenet64_classifier_guidance.sh:1-20: batch 100, 5000 images): sampling (hipGraph replay) + HIP Inception pool3 +
+float64 Gram + Frechet distance on the device; reports candidates/hour and the reference's reset / sample / fid_time split.
+
+After the timed region every workload produces one more, untimed batch and checks it (finite float sample, uint8 batch
+that is not constant; `output_check` in the JSON line): a non-finite batch makes bench.py exit non-zero.
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...` (one rank per GPU, RCCL): the batch shards by image with no data-path collective
@@ -37,18 +46,27 @@ PEAK_BF16_TFLOPS = 2500.0                  # dense MFMA bf16, MI355X_MICROARCH.m
 
 SCHEDULE_256 = [0, 200, 400, 600, 800]     # space_timesteps(1000, "ddim5"): the start candidate of `--time_step 5` (search_lsun_cat.sh:9)
 GFLOP_UNET_256 = 2242.87                   # ADM LSUN-256, per image per UNet eval
+GFLOP_UNET_128 = 614.69                    # ADM-G ImageNet-128, per image per UNet eval
+GFLOP_GUIDE_128 = 93.0                     # 128x128 classifier (depth 2): 46.5 GFLOP forward + as much backward-data
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch of the workload's dominant kernel, from the committed rocprofv3 --pmc passes of THIS round's
-    build (profiles/r02/pmc_dominant_kernel_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes over `bench.py --steps 1`
-    with the guide's gfx950 corrections, reduced by tools/pmc_summary.py).  PMC counters cannot be read inside the timed
-    run, so the figure is a measured constant of the build, refreshed whenever the kernel changes; None if absent."""
-    tp = os.path.join(ROOT, "profiles", "r02", "pmc_dominant_kernel_traffic.json")
-    if not os.path.exists(tp):
-        return None
-    with open(tp) as f:
-        return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    """(HBM bytes per launch of the workload's dominant kernel, where the figure comes from).  PMC counters cannot be read
+    inside the timed run: the figure is a COMMITTED constant of the build, measured by separate rocprofv3 `--pmc FETCH_SIZE`
+    / `--pmc WRITE_SIZE` passes over `bench.py --steps 1` with the guide's gfx950 corrections (tools/profile_round.sh,
+    tools/pmc_summary.py, tools/pmc_traffic_json.py) and refreshed whenever the kernel changes -- this round's file first,
+    the previous round's if this round has not re-collected the workload; (None, None) if absent.  The JSON line names the
+    file as `roofline.traffic_source`, so that a reader does not take it for a live measurement."""
+    for rnd in ("r03", "r02"):
+        tp = os.path.join(ROOT, "profiles", rnd, "pmc_dominant_kernel_traffic.json")
+        if not os.path.exists(tp):
+            continue
+        with open(tp) as f:
+            ent = json.load(f).get(workload)
+        if ent and ent.get("hbm_bytes_per_launch") is not None:
+            return ent["hbm_bytes_per_launch"], (f"committed constant: profiles/{rnd}/pmc_dominant_kernel_traffic.json "
+                                                 f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of that round's build; not read live)")
+    return None, None
 
 
 def adm256_flags():
@@ -58,6 +76,81 @@ def adm256_flags():
              learn_sigma=True, noise_schedule="linear", num_channels=256, num_head_channels=64, num_res_blocks=2,
              resblock_updown=True, use_fp16=True, use_scale_shift_norm=True, use_dynamic_unet=True)
     return d
+
+
+def adm128_flags():
+    """configs/128_guided_sample.sh:1 (the reference runs this model in fp32: `--use_fp16 False`; the HIP torso is 16-bit)."""
+    from autodiffusion_amd.script_util import model_and_diffusion_defaults
+    d = model_and_diffusion_defaults()
+    d.update(attention_resolutions="32,16,8", class_cond=True, image_size=128, learn_sigma=True, num_channels=256,
+             num_heads=4, num_res_blocks=2, resblock_updown=True, use_fp16=True, use_scale_shift_norm=True)
+    return d
+
+
+def auto_skip_layers(layer_num, steps, frac=0.1, seed=0):
+    """A deterministic layer-skip candidate in the shape the progressive joint search produces (search_dynamic_unet_..._
+    progressive.sh: `--max_prun 0.1`): every step skips round(frac * layer_num) layers drawn by a seeded RNG."""
+    import random
+    rng = random.Random(seed)
+    k = max(1, round(frac * layer_num))
+    return [sorted(rng.sample(range(layer_num), k)) for _ in range(steps)]
+
+
+def check_output(sample, u8):
+    """Untimed verification of one produced batch: finite float sample, uint8 NHWC batch that is an image (not constant).
+    -> the `output_check` object of the JSON line; raises SystemExit(3) on a non-finite or degenerate batch."""
+    ok_f = bool(torch.isfinite(sample).all().item())
+    u = u8.to(torch.float32)
+    std = float(u.std().item())
+    res = {"finite": ok_f, "u8_shape": list(u8.shape), "u8_checksum": int(u8.to(torch.int64).sum().item()),
+           "u8_mean": round(float(u.mean().item()), 3), "u8_std": round(std, 3),
+           "how": "one extra untimed batch after the timed region, same code path and seed schedule"}
+    if not ok_f or not (std > 0.0):
+        print(json.dumps({"error": "bench.py: the produced batch is non-finite or constant", "output_check": res}), flush=True)
+        raise SystemExit(3)
+    return res
+
+
+def pin_rank(local_rank, local_world):
+    """One process per GPU on one node: every rank issues ~3400 launches per step from ONE Python thread; a rank whose
+    launch thread is descheduled stalls its GPU queue and the MAX-over-ranks time.  Each rank gets its own contiguous slice of
+    the CPUs this job may use (sched_setaffinity) and a thread budget of that size for OMP / torch intra-op pools
+    (ADM_BENCH_AFFINITY=0 leaves the process alone).  -> description for the JSON line."""
+    if local_world <= 1 or os.environ.get("ADM_BENCH_AFFINITY", "1") == "0":
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    nthr = max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", len(mine)))))
+    os.environ["OMP_NUM_THREADS"] = str(nthr)
+    torch.set_num_threads(nthr)
+    return {"cpus": f"{mine[0]}-{mine[-1]}", "n_cpus": len(mine), "threads": nthr}
+
+
+def gather_ranks(world, rank, local_rank, dev, elapsed_local, pin, backend):
+    """Rank 0 collects (rank, device name, PCI bus id, CPU slice, per-rank elapsed seconds) from every rank and runs one
+    all-reduce of ones on the timing protocol's device: `RCCL saw N ranks` becomes a recorded fact of the JSON line."""
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(dev)
+    bus = None
+    if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev), "cuda_index": dev.index,
+          "pci_bus_id": bus, "uuid": str(getattr(props, "uuid", "")) or None, "elapsed_s": round(elapsed_local, 4),
+          "pid": os.getpid(), "cpu_affinity": pin}
+    every = [None] * world
+    dist.all_gather_object(every, me)
+    one = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(one)
+    return {"ranks": every, "collective_check": {"backend": dist.get_backend(), "allreduce_sum_of_ones": float(one.item()),
+                                                 "world_size": world}}
 
 
 def adm64_flags(class_cond=True, dynamic=False):
@@ -154,7 +247,7 @@ SD_CAND = [94, 217, 354, 574, 834, 944]     # GD/sample_imagenet64_classifier_gu
 SD_GFLOP_LATENT = 803.27                    # per latent per UNet evaluation
 
 
-def run_sd(args, rank, world, dev, red_dev):
+def run_sd(args, rank, world, dev, red_dev, pin=None):
     """BASELINE config 4: one step = one candidate-evaluation batch of the Stable-Diffusion example -- N latents
     [N, 4, 64, 64] sampled with K = 6 searched DDIM steps under classifier-free guidance 7.5 (2 UNet evaluations per
     step, batched as 2N latents) through the v1 latent UNet; random-init weights, synthetic 77 x 768 conditioning.
@@ -185,8 +278,9 @@ def run_sd(args, rank, world, dev, red_dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s_ in range(args.steps):
-        one_step(s_)
+        out = one_step(s_)
     torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -195,6 +289,15 @@ def run_sd(args, rank, world, dev, red_dev):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    rankinfo = gather_ranks(world, rank, int(os.environ.get("LOCAL_RANK", "0")), dev, elapsed_local, pin, args.dist_backend) if world > 1 else None
+    # the latents of the last timed step (outside the timed region): finite and not constant
+    lat_ok = bool(torch.isfinite(out).all().item())
+    lat_std = float(out.float().std().item())
+    chk = {"finite": lat_ok, "latent_shape": list(out.shape), "latent_mean": round(float(out.float().mean().item()), 5),
+           "latent_std": round(lat_std, 5), "how": "the last timed step's latents, checked after the timed region"}
+    if not lat_ok or not lat_std > 0.0:
+        print(json.dumps({"error": "bench.py --workload sd: non-finite or constant latents", "output_check": chk}), flush=True)
+        raise SystemExit(3)
     roof = None
     if not args.no_kernel_events:  # per-launch HIP events need the eager path: one untimed evaluation outside the graph
         unet.enable_graph(False)
@@ -208,9 +311,10 @@ def run_sd(args, rank, world, dev, red_dev):
         if dom:
             ms = sum(p[0].elapsed_time(p[1]) for p in dom)
             fl = sum(p[2] for p in dom)
+            tr, src = pmc_traffic("sd") if n == 6 else (None, None)
             roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)",
                     "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("sd"), "launches": len(dom),
+                    "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": tr, "traffic_source": src, "launches": len(dom),
                     "avg_launch_us": round(ms * 1e3 / len(dom), 2), "avg_launch_gflop": round(fl / len(dom) / 1e9, 3)}
     if rank == 0:
         value = world * n * args.steps / elapsed
@@ -219,7 +323,7 @@ def run_sd(args, rank, world, dev, red_dev):
             del unet, sampler
             torch.cuda.empty_cache()
             cpu = cpu_baseline(workload="sd")
-        print(json.dumps({
+        line = {
             "metric": "latents/sec (node), Stable-Diffusion v1 latent UNet, 6-step searched DDIM, guidance 7.5",
             "value": round(value, 2), "unit": "latents/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
@@ -230,7 +334,153 @@ def run_sd(args, rank, world, dev, red_dev):
                        "global_batch": world * n, "latent_size": 64, "sampler_steps": len(SD_CAND),
                        "parallelism": f"dp{world} (latent-sharded, no data-path collective)"},
             "model_tflops": round(value * 2 * len(SD_CAND) * SD_GFLOP_LATENT / 1e3, 1),
-            "roofline": roof, "cpu_baseline": cpu}), flush=True)
+            "roofline": roof, "output_check": chk, "cpu_baseline": cpu}
+        if rankinfo:
+            line.update(rankinfo)
+        print(json.dumps(line), flush=True)
+
+
+CAND_SEARCH_FLAGS = dict(batch_size=100, num_samples=5000)   # search_imagenet64_classifier_guidance.sh:2
+CAND_LIST = [[153, 424, 926, 690], [85, 305, 572, 856], [137, 441, 647, 971], [62, 333, 690, 902],
+             [201, 424, 744, 926], [17, 260, 519, 803]]        # 4-step candidates (the first = the headline schedule)
+
+
+def run_candidate(args, rank, world, dev, red_dev, pin):
+    """One step = ONE WHOLE candidate evaluation, `EvolutionSearcher.get_cand_fid(cand, args)` at the reference's own search
+    flags (search_imagenet64_classifier_guidance.sh:1-20, search_imagenet64_classifier_guidance.py:308-376): reset_diffusion,
+    5000 classifier-guided ADM-G-64 images in batches of 100 (hipGraph replay: at this batch the host's ~60 ms of launch
+    work per guided step is the floor otherwise), HIP Inception-v3 pool3 of every uint8 batch (random weights: the
+    checkpoint is not in the image), float64 Gram on the matrix cores, and the Frechet distance on the device
+    (`--fid_on_device`) against synthetic reference statistics.  N > 1: every rank evaluates its own candidate
+    (population-parallel, statistics local, no data-path collective): weak scaling, value = candidates of all ranks / time."""
+    import types
+    import numpy as np
+    import torch.distributed as dist
+    from autodiffusion_amd import logger, ops
+    from autodiffusion_amd.fid import FIDStatistics
+    from autodiffusion_amd.inception import pool3_features
+    from autodiffusion_amd.script_util import (args_to_dict, classifier_defaults, create_classifier,
+                                               create_model_and_diffusion, model_and_diffusion_defaults)
+    from autodiffusion_amd.search import EvolutionSearcher
+    bs = args.batch or CAND_SEARCH_FLAGS["batch_size"]
+    nimg = args.images or CAND_SEARCH_FLAGS["num_samples"]
+    flags = adm64_flags(class_cond=True)
+    model, diffusion = create_model_and_diffusion(**args_to_dict(argparse.Namespace(**flags), model_and_diffusion_defaults().keys()))
+    model.to(dev).randomize_(1234).convert_to_fp16()
+    model.set_torso(args.torso)
+    cf = classifier_defaults()
+    cf.update(image_size=64, classifier_depth=4)
+    classifier = create_classifier(**cf)
+    classifier.to(dev).randomize_(4321)
+    features, dim = pool3_features(dev, "", "tf1", allow_random=True)
+    rng = np.random.RandomState(0)
+    a = rng.randn(dim, dim) / 45.0
+    ref = FIDStatistics(rng.randn(dim) * 0.1, a @ a.T + 0.1 * np.eye(dim))
+    use_graph = not args.no_graph and bs <= 128
+    sargs = types.SimpleNamespace(max_epochs=1, select_num=10, population_num=50, m_prob=0.25, crossover_num=15, mutation_num=25,
+                                  batch_size=bs, num_samples=nimg, image_size=64, use_ddim=True, clip_denoised=True,
+                                  class_cond=True, classifier_scale=1.0, seed=0, time_step=4, use_ddim_init_x=True,
+                                  fid_on_device=True, use_graph=use_graph)
+    logger.log = lambda *a_, **k_: None   # the reference's per-batch "created N samples" lines go to log.txt in a search; not here
+    searcher = EvolutionSearcher(sargs, model, diffusion, 4, classifier=classifier, features=features, feature_dim=dim,
+                                 ref_stats=ref, population_parallel=True)
+
+    def one_step(idx):
+        cand = CAND_LIST[(idx * world + rank) % len(CAND_LIST)]
+        fid = searcher.get_cand_fid(cand=cand, args=sargs)
+        return fid, dict(searcher.last_times)
+    for w in range(args.warmup):   # a warm-up candidate of a few batches: graph capture, kernel attributes, allocator pools
+        sargs.num_samples = min(nimg, 3 * bs)
+        one_step(-1 - w)
+        sargs.num_samples = nimg
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    splits, fids = [], []
+    for s_ in range(args.steps):
+        fid, tm = one_step(s_)
+        fids.append(fid)
+        splits.append(tm)
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if not all(np.isfinite(fids)):
+        print(json.dumps({"error": "bench.py --workload candidate: non-finite FID", "fids": [float(f) for f in fids]}), flush=True)
+        raise SystemExit(3)
+    rankinfo = gather_ranks(world, rank, int(os.environ.get("LOCAL_RANK", "0")), dev, elapsed_local, pin, args.dist_backend) if world > 1 else None
+    # output check + roofline of the dominant kernel at this batch: one eager batch after the timed region
+    ev = searcher._ev
+    model.enable_graph(False)
+    classifier.enable_graph(False)
+    ev.set_candidate(CAND_LIST[0])
+    roof = None
+    if not args.no_kernel_events:
+        ops.CONV_PROFILE, ops.CONV_PROFILE_KEY = [], (5, 9, True, 2)
+    t0e = time.perf_counter()
+    u8, sample = ev.sample_batch(bs, seed=12345 + rank, return_float=True)
+    torch.cuda.synchronize()
+    eager_s = time.perf_counter() - t0e
+    if ops.CONV_PROFILE is not None:
+        prof, ops.CONV_PROFILE, ops.CONV_PROFILE_KEY = ops.CONV_PROFILE, None, None
+        if prof:
+            ms = sum(p_[0].elapsed_time(p_[1]) for p_ in prof)
+            fl = sum(p_[2] for p_ in prof)
+            tr, src = pmc_traffic("guided")
+            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)",
+                    "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None if tr is None else round(tr * bs / 256.0), "traffic_source":
+                        None if tr is None else src + f"; measured at batch 256 and scaled by {bs}/256 (the kernel's traffic is linear in the batch)",
+                    "launches": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),
+                    "avg_launch_gflop": round(fl / len(prof) / 1e9, 3),
+                    "how": f"one eager batch of {bs} after the timed region (the timed candidates replay hipGraphs, which carry no events), "
+                           f"{eager_s * 1e3:.0f} ms with per-launch events"}
+    chk = check_output(sample, u8)
+    if rank == 0:
+        ncand = world * args.steps
+        per_cand = elapsed / args.steps
+        mean = lambda k: float(np.mean([t_[k] for t_ in splits]))   # noqa: E731
+        gflop_img = len(CAND_LIST[0]) * (GFLOP_UNET + GFLOP_GUIDE)
+        out = {
+            "metric": "candidates/hour (node): one whole get_cand_fid (ADM-G ImageNet-64, 4-step guided DDIM, 5000 images, Inception pool3 + FID)",
+            "value": round(ncand / elapsed * 3600.0, 1), "unit": "candidates/hour", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(per_cand * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.torso == "bf16" else "f16",
+            "data": "synthetic (x_T ~ N(0,1), y ~ U{0..999}, random-init weights of the ADM-G-64, classifier and Inception-v3 architectures, "
+                    "synthetic reference statistics): the FID VALUES mean nothing, the work is the real candidate's",
+            "config": {"workload": f"get_cand_fid at the reference's search flags (search_imagenet64_classifier_guidance.sh: batch_size {bs}, "
+                                   f"num_samples {nimg}, 4-step candidates, classifier_scale 1.0), {args.torso}, "
+                                   f"{'hipGraph replay' if use_graph else 'eager launches'}, HIP Inception pool3 + f64 Gram + on-device Frechet distance",
+                       "global_batch": world * bs, "image_size": 64, "sampler_steps": 4, "images_per_candidate": nimg,
+                       "parallelism": f"dp{world} (population-parallel: one whole candidate per rank and step, no data-path collective)",
+                       "launch": "hipGraph replay" if use_graph else "eager"},
+            "images_per_sec": round(ncand * nimg / elapsed, 1),
+            "model_tflops": round(ncand * nimg / elapsed * gflop_img / 1e3, 1),
+            "time_split_s": {"reset_time": round(mean("reset_time"), 4), "sample_time": round(mean("sample_time"), 3),
+                             "fid_time": round(mean("fid_time"), 3), "per_candidate": round(per_cand, 3),
+                             "note": "rank 0's mean over the timed candidates, the reference's own three timers "
+                                     "(search_imagenet64_classifier_guidance.py:311, 366, 374); sample_time includes the Inception + Gram "
+                                     "launches queued behind each batch, fid_time = pooled statistics + two f64 eigh + the scalar's D2H"},
+            "fid_values": [round(float(f), 4) for f in fids],
+            "roofline": roof, "output_check": chk,
+        }
+        if rankinfo:
+            out.update(rankinfo)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+            v = out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["note"] = (f"sampling only, unguided, BASELINE config 1 (images/sec); a {nimg}-image guided candidate at that rate "
+                                           f"is > {nimg / max(v, 1e-9) / 3600.0:.1f} host-hours")
+        print(json.dumps(out), flush=True)
 
 
 def main():
@@ -238,11 +488,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=None, help="images per step and GPU (default 256; --workload sd: 6 latents)")
-    ap.add_argument("--workload", default="auto", choices=["auto", "guided", "unguided", "adm256", "sd"],
-                    help="auto/guided = the headline (ADM-G ImageNet-64, BASELINE configs[1]); adm256 = ADM LSUN-256 dynamic UNet, "
-                         "uniform 5-step DDIM (the north star's 256x256 line); sd = BASELINE config 4 "
-                         "(Stable-Diffusion v1 latent UNet, 6 searched DDIM steps, classifier-free guidance 7.5)")
+    ap.add_argument("--batch", type=int, default=None, help="images per step and GPU (default 256; adm128: 32; adm256: 64; "
+                                                            "--workload sd: 6 latents; candidate: 100 per sampling batch)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "guided", "unguided", "adm128", "adm256", "sd", "candidate"],
+                    help="auto/guided = the headline (ADM-G ImageNet-64, BASELINE configs[1]); adm128 = ADM-G ImageNet-128 guided, "
+                         "10-step candidate (configs[2]'s per-GPU unit); adm256 = ADM LSUN-256 dynamic UNet, uniform 5-step DDIM (the north "
+                         "star's 256x256 line; + --skip-layers / --with-fid = configs[4]); sd = configs[3] (Stable-Diffusion v1 latent "
+                         "UNet, 6 searched DDIM steps, classifier-free guidance 7.5); candidate = one whole get_cand_fid per step")
+    ap.add_argument("--skip-layers", default=None,
+                    help="dynamic-UNet workloads (adm256): one layer-skip list per step, as JSON ('[[1,5],[],...]'), or 'auto' = "
+                         "10 %% of the layers per step, seeded (the shape `--max_prun 0.1` candidates have)")
+    ap.add_argument("--images", type=int, default=None, help="--workload candidate: images per candidate (default 5000)")
+    ap.add_argument("--no-graph", action="store_true", help="--workload candidate: eager launches instead of hipGraph replay")
     ap.add_argument("--torso", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type of the UNet torso: bf16 (BASELINE configs[1] names it) or fp16 (the reference's own "
                          "torso type, libadm_hip_f16.so: same kernels, 11 mantissa bits; the classifier's backward network stays bf16)")
@@ -265,9 +522,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    pin = pin_rank(local_rank, local_world)   # before any thread pool exists
     dev = torch.device(f"cuda:{local_rank % max(1, torch.cuda.device_count())}")
     torch.cuda.set_device(dev)
     if world > 1:
@@ -279,31 +538,36 @@ def main():
             dist.init_process_group(backend="gloo", init_method="env://")
     red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
-    if args.workload == "sd":
-        run_sd(args, rank, world, dev, red_dev)
+    if args.workload in ("sd", "candidate"):
+        (run_sd if args.workload == "sd" else run_candidate)(args, rank, world, dev, red_dev, pin)
         if world > 1:
             dist.destroy_process_group()
         return
-    w256 = args.workload == "adm256"
+    w256, w128 = args.workload == "adm256", args.workload == "adm128"
     if args.batch is None:
         # 256x256: 64 images per step = 0.7 s of GPU time; the reference's own launch flag is 36 (search_lsun_cat.sh:2) and
-        # throughput is flat beyond (every launch already fills the chip), so "as large as fits" would only stretch the run
-        args.batch = 64 if w256 else 256
+        # throughput is flat beyond (every launch already fills the chip), so "as large as fits" would only stretch the run;
+        # 128x128: the reference's launch flag (configs/128_guided_sample.sh:3)
+        args.batch = 64 if w256 else (32 if w128 else 256)
 
     from autodiffusion_amd import ops
     from autodiffusion_amd.evaluate import CandidateEvaluator
+    from autodiffusion_amd.schedule import space_timesteps
     from autodiffusion_amd.script_util import (args_to_dict, classifier_defaults, create_classifier,
                                                create_model_and_diffusion, model_and_diffusion_defaults)
 
-    guided = args.workload in ("auto", "guided")
-    flags = adm256_flags() if w256 else adm64_flags(class_cond=True)
-    size = 256 if w256 else 64
-    schedule = SCHEDULE_256 if w256 else SCHEDULE
-    gflop_unet = GFLOP_UNET_256 if w256 else GFLOP_UNET
+    guided = args.workload in ("auto", "guided", "adm128")
+    flags = adm256_flags() if w256 else (adm128_flags() if w128 else adm64_flags(class_cond=True))
+    size = 256 if w256 else (128 if w128 else 64)
+    # adm128: the uniform 10-step grid, the start candidate of a `--time_step 10` search (the candidate's cost does not depend
+    # on which timesteps it holds)
+    schedule = SCHEDULE_256 if w256 else (sorted(space_timesteps(1000, "ddim10")) if w128 else SCHEDULE)
+    gflop_unet = GFLOP_UNET_256 if w256 else (GFLOP_UNET_128 if w128 else GFLOP_UNET)
+    gflop_guide = GFLOP_GUIDE_128 if w128 else GFLOP_GUIDE
     # the launch mix's dominant conv symbol: (tiling variant, taps, map > 8x8, prologue) -- 192-wide tiles for ADM-64's
-    # multiples of 192 channels, 128-wide tiles for LSUN-256's multiples of 256
-    dom_key = (6, 9, True, 2) if w256 else (5, 9, True, 2)
-    dom_name = ("conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)" if w256 else
+    # multiples of 192 channels, 128-wide tiles for the 256-multiples of ADM-128 / LSUN-256
+    dom_key = (6, 9, True, 2) if (w256 or w128) else (5, 9, True, 2)
+    dom_name = ("conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)" if (w256 or w128) else
                 "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)")
     model, diffusion = create_model_and_diffusion(**args_to_dict(argparse.Namespace(**flags),
                                                                  model_and_diffusion_defaults().keys()))
@@ -313,19 +577,29 @@ def main():
     if guided:
         try:
             cf = classifier_defaults()
-            cf.update(image_size=64, classifier_depth=4)
+            cf.update(image_size=size, classifier_depth=2 if w128 else 4)   # configs/128_guided_sample.sh:2 / search_imagenet64...sh:6
             classifier = create_classifier(**cf)
             classifier.to(dev).randomize_(4321)
             if not hasattr(classifier, "log_prob_grad"):
                 raise NotImplementedError
         except (ImportError, NotImplementedError):
-            if args.workload == "guided":
+            if args.workload in ("guided", "adm128"):
                 raise
             classifier, guided = None, False
 
     ev = CandidateEvaluator(model, diffusion, classifier=classifier, image_size=size, use_ddim=True,
                             classifier_scale=1.0, class_cond=not w256, device=dev, use_graph=args.graph)
-    ev.set_candidate(schedule)
+    skip_layers = None
+    if args.skip_layers:
+        if not getattr(model.plan, "dynamic", False):
+            raise SystemExit("--skip-layers needs a dynamic-UNet workload (adm256)")
+        skip_layers = (auto_skip_layers(model.layer_num, len(schedule)) if args.skip_layers == "auto"
+                       else json.loads(args.skip_layers))
+        if len(skip_layers) != len(schedule):
+            raise SystemExit(f"--skip-layers: {len(skip_layers)} lists for {len(schedule)} steps")
+        ev.set_candidate({"timesteps": list(schedule), "skip_layers": skip_layers})
+    else:
+        ev.set_candidate(schedule)
     B = args.batch
 
     fid_net = fid_acc = None
@@ -336,12 +610,13 @@ def main():
         fid_net.weights_loaded = True     # random weights on purpose (throughput run): no warning
         fid_acc = ActivationAccumulator(2048, dev)
 
-    def one_step(step_idx):
+    def one_step(step_idx, return_float=False):
         # deterministic, layout-independent seeding per (step, rank)
-        u8 = ev.sample_batch(B, seed=(1000003 * step_idx + rank))
+        res = ev.sample_batch(B, seed=(1000003 * step_idx + rank), return_float=return_float)
+        u8 = res[0] if return_float else res
         if fid_net is not None:
             fid_acc.add_from(fid_net.features, u8)
-        return u8
+        return res
 
     for w in range(args.warmup):
         one_step(-1 - w)
@@ -358,6 +633,7 @@ def main():
     for s in range(args.steps):
         one_step(s)
     torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -366,6 +642,23 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    fid_pooled = None
+    if fid_acc is not None and w256:
+        # BASELINE config 5's pooled-FID stage: ONE all-gather of the packed float64 (n, sum a, sum a a^T) over the ranks (RCCL over
+        # xGMI; a no-op at N = 1) + the Frechet distance on the device; timed on its own, outside the sampling steps
+        import numpy as np
+        from autodiffusion_amd.fid import FIDStatistics
+        rng = np.random.RandomState(0)
+        a_ = rng.randn(2048, 2048) / 45.0
+        ref = FIDStatistics(rng.randn(2048) * 0.1, a_ @ a_.T + 0.1 * np.eye(2048))
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        fidv = fid_acc.frechet_distance_device(ref)
+        torch.cuda.synchronize()
+        fid_pooled = {"images_pooled": world * B * (args.steps + args.warmup), "seconds": round(time.perf_counter() - tf0, 4),
+                      "finite": bool(fidv == fidv and abs(fidv) != float("inf")),
+                      "what": "packed f64 all-gather of (n, s1, s2) over the ranks + on-device Frechet distance (two f64 eigh), once per candidate"}
+    rankinfo = gather_ranks(world, rank, local_rank, dev, elapsed_local, pin, args.dist_backend) if world > 1 else None
 
     roof = None
     if args.graph and not args.no_kernel_events:   # the replayed launches carry no events: one eager batch for the roofline
@@ -394,10 +687,12 @@ def main():
             ms = sum(p[0].elapsed_time(p[1]) for p in dom)
             fl = sum(p[2] for p in dom)
             achieved = fl / (ms * 1e-3) / 1e12
-            traffic = pmc_traffic("adm256" if w256 else ("guided" if guided else "unguided"))
+            traffic, traffic_src = pmc_traffic(args.workload if args.workload != "auto" else "guided")
+            if traffic is not None and B != {"adm256": 64, "adm128": 32}.get(args.workload, 256):
+                traffic, traffic_src = None, None   # the committed figure is for the default batch
             roof = {"bound": "mfma", "kernel": dom_name,
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches": len(dom), "avg_launch_us": round(ms * 1e3 / len(dom), 2),
                     "avg_launch_gflop": round(fl / len(dom) / 1e9, 3),
                     "share_of_step_time": round(ms * 1e-3 / (eager_s if args.graph else elapsed), 3)}
@@ -421,39 +716,57 @@ def main():
                                     "frac": round(ifl / (ims * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                     "avg_launch_us": round(ims * 1e3 / len(iso), 2), "launches": len(iso),
                                     "how": "one untimed batch after the timed region, networks in sequence on one stream"}
+    ops.CONV_PROFILE = None
+    # what the timed loop produces, verified on one more batch outside the timed region
+    u8c, samplec = one_step(args.steps + 2, return_float=True)
+    torch.cuda.synchronize()
+    chk = check_output(samplec, u8c)
 
     if rank == 0:
         imgs = world * B * args.steps
         value = imgs / elapsed
-        gflop_img = len(schedule) * (gflop_unet + (GFLOP_GUIDE if guided else 0.0))
+        gflop_img = len(schedule) * (gflop_unet + (gflop_guide if guided else 0.0))
         if w256:
             wl = (f"ADM LSUN-256 dynamic UNet (552.8 M), unconditional, uniform {len(schedule)}-step DDIM {schedule}, "
-                  f"batch={B} per GPU, {args.torso}")
+                  f"batch={B} per GPU, {args.torso}" + (f", layer-skip lists {skip_layers}" if skip_layers else ""))
+        elif w128:
+            wl = (f"ADM-G ImageNet-128 (421.5 M UNet, 128x128 depth-2 classifier) classifier-guided, {len(schedule)}-step DDIM "
+                  f"{schedule}, batch={B} per GPU, {args.torso}")
         else:
             wl = (("ADM-G ImageNet-64 classifier-guided" if guided else
                    "ADM ImageNet-64 class-conditional, UNGUIDED (classifier guidance not in this run)")
                   + f", searched 4-step DDIM {schedule}, batch={B} per GPU, {args.torso}")
         out = {
             "metric": ("images/sec (node), ADM LSUN-256 5-step DDIM" if w256 else
-                       "images/sec (node), ADM-G ImageNet-64 4-step DDIM"),
+                       ("images/sec (node), ADM-G ImageNet-128 10-step DDIM" if w128 else
+                        "images/sec (node), ADM-G ImageNet-64 4-step DDIM")),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.torso == "bf16" else "f16",
             "data": ("synthetic (x_T ~ N(0,1), random-init weights of the ADM LSUN-256 architecture)" if w256 else
-                     "synthetic (x_T ~ N(0,1), y ~ U{0..999}, random-init weights of the ADM-G-64 architecture)"),
+                     f"synthetic (x_T ~ N(0,1), y ~ U{{0..999}}, random-init weights of the ADM-G-{size} architecture)"),
             "config": {"workload": wl,
                        "global_batch": world * B, "image_size": size, "sampler_steps": len(schedule),
                        "parallelism": f"dp{world} (image-sharded, no data-path collective)",
                        "launch": "hipGraph replay" if args.graph else "eager",
                        "fid_stage_in_step": bool(args.with_fid)},
             "model_tflops": round(value * gflop_img / 1e3, 1),
-            "roofline": roof,
+            "roofline": roof, "output_check": chk,
         }
+        if skip_layers:
+            skipped = sum(len(s_) for s_ in skip_layers)
+            out["config"]["skip_layers"] = skip_layers
+            out["model_tflops"] = None   # the per-layer FLOPs of the skipped layers are not tabulated: no TFLOP/s claim
+            out["config"]["layers_evaluated"] = f"{len(schedule) * model.layer_num - skipped} of {len(schedule) * model.layer_num}"
+        if fid_pooled:
+            out["fid_pooled"] = fid_pooled
+        if rankinfo:
+            out.update(rankinfo)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-            if w256:
-                out["cpu_baseline"]["note"] = ("timed on BASELINE config 1 (64x64): one 256x256 evaluation is 2242.9 GFLOP, "
-                                               "10.2 x a 64x64 one, too long for a bounded sample of this workload")
+            if w256 or w128:
+                out["cpu_baseline"]["note"] = (f"timed on BASELINE config 1 (64x64): one {size}x{size} evaluation is {gflop_unet:.1f} GFLOP, "
+                                               f"{gflop_unet / GFLOP_UNET:.1f} x a 64x64 one, too long for a bounded sample of this workload")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

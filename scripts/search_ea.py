@@ -8,7 +8,9 @@ Result lines ("epoch = i : top k result", "No.j [..] fid = ..") go to ``<save_di
 
 FID features: by default the bundled HIP Inception-v3 pool3 extractor (autodiffusion_amd/inception.py) with the weights
 named by ``--inception_path`` (the pt_inception-2015-12-05 state_dict the reference's evaluator stack downloads; it is
-not in this image -- without it the extractor runs on random weights and says so).  ``--features pkg.module:factory``
+not in this image).  With neither ``--features`` nor ``--inception_path`` the CLI exits: a search that ranks candidates on
+random-weight features is meaningless; ``--inception_random True`` opts in for throughput runs and tests, and every FID line
+of log.txt is then tagged "FID on RANDOM Inception weights".  ``--features pkg.module:factory``
 swaps in any callable ``factory(device) -> (features, dim)`` with ``features(uint8 NHWC device batch) -> fp32 [B, dim]``.
 ``--ref_path`` is an .npz with ``mu``, ``sigma`` (written from the reference's pickled FIDStatistics).  ``--use_graph True`` replays each UNet evaluation / guidance gradient as a captured hipGraph (batches <= ~100 are
 bound by the host launch rate otherwise).  ``--population_parallel True`` shards whole
@@ -44,7 +46,7 @@ def create_argparser():
         time_step=100, seed=0, deterministic=False, local_rank=0, max_epochs=20, select_num=10, population_num=50,
         m_prob=0.1, crossover_num=25, mutation_num=35, classifier_path="", classifier_scale=1.0, max_fid=48.0,
         thres=0.2, use_ddim_init_x=False, search_space="", ref_path="", MASTER_PORT="12344", init_x="",
-        without_classifier=False, features="", inception_path="", inception_input="tf1", population_parallel=False, fid_on_device=False, use_graph=False,
+        without_classifier=False, features="", inception_path="", inception_input="tf1", inception_random=False, population_parallel=False, fid_on_device=False, use_graph=False,
         index_step=None, max_prun=0.0, min_prun=0.0,
     )
     defaults.update(model_and_diffusion_defaults())
@@ -99,7 +101,15 @@ def main(argv=None):
         features, dim = getattr(importlib.import_module(mod), fn)(dist_util.dev())
     else:
         from autodiffusion_amd.inception import pool3_features
-        features, dim = pool3_features(dist_util.dev(), args.inception_path, args.inception_input)
+        if not args.inception_path and not args.inception_random:
+            raise SystemExit("search_ea.py: give --inception_path (the pt_inception-2015-12-05 state_dict) or --features "
+                             "pkg.module:factory; FID on random Inception weights ranks candidates on a meaningless metric "
+                             "(--inception_random True opts in for throughput runs and tests)")
+        features, dim = pool3_features(dist_util.dev(), args.inception_path, args.inception_input,
+                                       allow_random=args.inception_random)
+        if args.inception_random and not args.inception_path:
+            logger.log("WARNING: FID features come from an Inception-v3 with RANDOM weights (--inception_random True): "
+                       "every fid value below is NOT a quality metric")
     search_space = build_search_space(args, diffusion)
     if search_space is not None:
         logger.log("search space: " + str(search_space))

@@ -1,0 +1,62 @@
+"""CPU: the host-side pieces of bench.py that do not need a GPU -- the layer-skip candidate generator, the output check
+that makes a non-finite batch fatal, the per-rank CPU pinning policy and the traffic-source bookkeeping."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_auto_skip_layers_is_deterministic_and_in_range():
+    a = bench.auto_skip_layers(58, 5)
+    assert a == bench.auto_skip_layers(58, 5) and len(a) == 5
+    assert all(len(s) == 6 and s == sorted(set(s)) and 0 <= s[0] and s[-1] < 58 for s in a)
+    assert len({tuple(s) for s in a}) > 1          # the steps do not all skip the same layers
+
+
+def test_check_output_passes_images_and_rejects_nan_or_constant_batches(capsys):
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (4, 8, 8, 3), generator=g, dtype=torch.uint8)
+    ok = bench.check_output(torch.randn(4, 3, 8, 8, generator=g), u8)
+    assert ok["finite"] is True and ok["u8_shape"] == [4, 8, 8, 3] and ok["u8_checksum"] == int(u8.long().sum()) and ok["u8_std"] > 0
+    bad = torch.randn(4, 3, 8, 8, generator=g)
+    bad[1, 2, 3, 4] = float("nan")
+    with pytest.raises(SystemExit) as e:
+        bench.check_output(bad, u8)
+    assert e.value.code == 3 and "non-finite" in capsys.readouterr().out
+    with pytest.raises(SystemExit):
+        bench.check_output(torch.zeros(4, 3, 8, 8), torch.full((4, 8, 8, 3), 127, dtype=torch.uint8))
+
+
+def test_pin_rank_gives_each_local_rank_its_own_cpu_slice():
+    assert bench.pin_rank(0, 1) is None      # one rank: the process is left alone
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs >= 2 CPUs and sched_setaffinity")
+    code = ("import json, os, sys; sys.path.insert(0, %r); import bench; "
+            "print(json.dumps([bench.pin_rank(int(sys.argv[1]), 2), sorted(os.sched_getaffinity(0)), os.environ.get('OMP_NUM_THREADS')]))" % ROOT)
+    got = []
+    for lr in (0, 1):
+        env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}
+        r = subprocess.run([sys.executable, "-c", code, str(lr)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    (p0, c0, t0), (p1, c1, t1) = got
+    assert p0["n_cpus"] == len(c0) and p1["n_cpus"] == len(c1) and not set(c0) & set(c1)
+    assert int(t0) == p0["threads"] >= 1 and int(t1) == p1["threads"] >= 1
+    env = dict(os.environ, ADM_BENCH_AFFINITY="0")
+    r = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert json.loads(r.stdout.strip().splitlines()[-1])[0] is None
+
+
+def test_pmc_traffic_names_its_source():
+    v, src = bench.pmc_traffic("guided")
+    assert (v is None) == (src is None)
+    if v is not None:
+        assert v > 0 and "committed constant" in src and "profiles/r0" in src
+    assert bench.pmc_traffic("no-such-workload") == (None, None)

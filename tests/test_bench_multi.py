@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("workload", ["guided", "sd"])
+@pytest.mark.parametrize("workload", ["guided", "sd", "adm256"])
 def test_bench_two_ranks_prints_one_consistent_json_line(workload):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -35,6 +35,16 @@ def test_bench_two_ranks_prints_one_consistent_json_line(workload):
     assert out["dtype"] == "bf16" and "synthetic" in out["data"] and out["value"] > 0
     # value = units all ranks processed / the (max-over-ranks) time of the K timed steps
     assert abs(out["value"] - 2 * batch / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]
+    # the line describes the ranks it timed: who ran where, each rank's own elapsed time, and one all-reduce over the group
+    ranks = out["ranks"]
+    assert [r_["rank"] for r_ in ranks] == [0, 1] and len({r_["pid"] for r_ in ranks}) == 2
+    assert all(r_["device"] and r_["elapsed_s"] > 0 for r_ in ranks)
+    assert max(r_["elapsed_s"] for r_ in ranks) <= out["ms_per_step"] * 1e-3 * out["steps"] * 1.001 + 1e-3   # MAX over ranks (+ barrier)
+    assert out["collective_check"] == {"backend": "gloo", "allreduce_sum_of_ones": 2.0, "world_size": 2}
+    aff = [r_["cpu_affinity"] for r_ in ranks]
+    if all(a is not None for a in aff):   # disjoint CPU slices, one per rank
+        assert aff[0]["cpus"] != aff[1]["cpus"] and all(a["threads"] >= 1 for a in aff)
+    assert out["output_check"]["finite"] is True
 
 
 def test_bench_single_rank_line_with_the_fid_stage_and_roofline():
@@ -53,3 +63,30 @@ def test_bench_single_rank_line_with_the_fid_stage_and_roofline():
     roof = out["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
     assert 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["launches"] > 0
+    assert "traffic_source" in roof and (roof["traffic"] is None) == (roof["traffic_source"] is None)
+    chk = out["output_check"]
+    assert chk["finite"] is True and chk["u8_shape"] == [8, 64, 64, 3] and chk["u8_std"] > 0
+
+
+def test_bench_candidate_workload_line():
+    """--workload candidate: one whole get_cand_fid per step (here 24 images in batches of 8) -> candidates/hour with the
+    reference's reset / sample / fid_time split, finite FIDs, the output check and the roofline of one eager batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "candidate", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--images", "24", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["unit"] == "candidates/hour" and out["n_gpus"] == 1 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["images_per_candidate"] == 24 and out["config"]["launch"] == "hipGraph replay"
+    ts = out["time_split_s"]
+    assert ts["sample_time"] > 0 and ts["fid_time"] > 0 and ts["reset_time"] >= 0
+    assert abs(ts["per_candidate"] - out["ms_per_step"] * 1e-3) < 1e-2
+    assert ts["reset_time"] + ts["sample_time"] + ts["fid_time"] <= ts["per_candidate"] * 1.05 + 0.05
+    assert abs(out["value"] - 3600.0 / ts["per_candidate"]) <= 0.02 * out["value"]
+    assert abs(out["images_per_sec"] - 24 / ts["per_candidate"]) <= 0.02 * out["images_per_sec"] + 0.1
+    assert len(out["fid_values"]) == 2 and all(f == f for f in out["fid_values"])
+    assert out["output_check"]["finite"] is True and out["roofline"]["launches"] > 0

@@ -114,8 +114,9 @@ def test_timestep_embedding(ops):
 
 
 def _linear_path(n, k):
-    """Which of adm_linear_f32's three kernels serves n rows (csrc/adm_embed.hip): matrix-pipe, GEMV-shaped, 64x64 tile."""
-    if k % 16 == 0 and n >= 32:
+    """Which of adm_linear_f32's three kernels serves n rows (csrc/adm_embed.hip): matrix-pipe (chosen by k alone, so that a
+    row's bits never depend on the batch it rides in), GEMV-shaped, 64x64 tile."""
+    if k % 16 == 0:
         return "mfma"
     return "small" if n <= 64 and k % 4 == 0 else "tile"
 
@@ -133,6 +134,8 @@ def test_linear_f32(ops, n, k, o):
     torch.testing.assert_close(got, F.linear(x, w), rtol=1e-4, atol=1e-4)
     if n >= 4 and _linear_path(n, k) == _linear_path(n - n // 2, k):  # a row's result does not depend on where it sits in the batch (same kernel)
         assert torch.equal(ops.linear_f32(x[n // 2:].contiguous().to(DEV), w.to(DEV), None).cpu(), got[n // 2:])
+    if k % 16 == 0:   # ... nor on how many rows ride along: 2 rows alone == the first 2 of n (the matrix-pipe kernel at any n)
+        assert torch.equal(ops.linear_f32(x[:2].contiguous().to(DEV), w.to(DEV), None).cpu(), got[:2])
 
 
 # ------------------------------------------------------------------ stem / GN / resample

@@ -178,3 +178,43 @@ def test_hipgraph_replay_of_unet_and_guidance_gradient_is_bit_identical():
     assert len(model._packed.graphs) >= 3 and len(clf._packed.graphs) >= 1     # {no skips, [1], [0, 5]} x streams
     model.enable_graph(False)
     clf.enable_graph(False)
+
+
+def test_graph_cache_grows_with_the_candidates_distinct_skip_sets():
+    """A dynamic-UNet candidate carries one skip list per step: with more distinct lists than the LRU holds every evaluation
+    of every batch would miss and recapture (the round-2 advisor's finding).  set_candidate() sizes the cache to the
+    candidate (<= GRAPH_CACHE_MAX), so the second batch of a 14-set candidate is pure replay; beyond the cap the candidate
+    runs eagerly.  Results equal the eager path's bitwise either way."""
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    model, diffusion, _ = _setup_m64()
+    L = model.layer_num
+    steps = sorted(range(40, 40 + 14 * 60, 60))
+    import itertools
+    skips = [list(c) for c in itertools.islice(itertools.combinations(range(L), 2), 14)]   # 14 distinct sets > the default LRU of 12
+    assert len(skips) == 14
+    cand = {"timesteps": steps, "skip_layers": skips}
+    model.enable_graph(False)
+    ev = CandidateEvaluator(model, diffusion, None, image_size=64, use_ddim=True, device=DEV, use_graph=False)
+    ev.set_candidate(cand)
+    want = ev.sample_batch(2, seed=9).clone()
+    evg = CandidateEvaluator(model, diffusion, None, image_size=64, use_ddim=True, device=DEV, use_graph=True)
+    evg.set_candidate(cand)
+    assert model.GRAPH_CACHE >= 14 and not model._graph_eager
+    assert torch.equal(evg.sample_batch(2, seed=9), want)
+    keys = list(model._packed.graphs.keys())
+    assert len(keys) == 14
+    assert torch.equal(evg.sample_batch(2, seed=9), want)
+    assert list(model._packed.graphs.keys()) == keys            # second batch: no eviction, no recapture
+    # beyond the cap: eager evaluation (one log line), no thrash
+    model.GRAPH_CACHE_MAX, old = 4, model.GRAPH_CACHE_MAX
+    try:
+        evg.set_candidate(cand)
+        assert model._graph_eager
+        assert torch.equal(evg.sample_batch(2, seed=9), want)
+        assert list(model._packed.graphs.keys()) == keys
+        evg.set_candidate(steps[:4])                            # a plain candidate fits again
+        assert not model._graph_eager
+    finally:
+        model.GRAPH_CACHE_MAX = old
+        model.GRAPH_CACHE = type(model).GRAPH_CACHE
+        model.enable_graph(False)

@@ -57,7 +57,7 @@ def test_search_cli_one_rank_vs_image_sharded_vs_population_parallel(tmp_path):
     assert log2.count("epoch = 0 : top") == 1
 
 
-def _run_bundled(tmp_path, tag, nproc):
+def _run_bundled(tmp_path, tag, nproc, opt_in=True):
     ref = str(tmp_path / "ref2048.npz")
     if not os.path.exists(ref):
         rng = np.random.RandomState(0)
@@ -70,15 +70,22 @@ def _run_bundled(tmp_path, tag, nproc):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "scripts", "search_ea.py")] + flags + [
-               "--save_dir", save, "--ref_path", ref, "--fid_on_device", "True", "--max_epochs", "1"]
+               "--save_dir", save, "--ref_path", ref, "--fid_on_device", "True", "--max_epochs", "1"] + (
+                   ["--inception_random", "True"] if opt_in else [])
     env = dict(os.environ, ADM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4",
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    if not opt_in:   # neither --features nor --inception_path: the CLI refuses to rank candidates on random-weight features
+        assert r.returncode != 0 and "--inception_random" in r.stderr, r.stderr[-2000:]
+        return None
     assert r.returncode == 0, r.stderr[-3000:]
-    assert "RANDOM weights" in r.stderr
     log = open(os.path.join(save, "log.txt")).read()
-    top = re.findall(r"^No\.(\d+) (\[.*?\]) fid = ([-0-9.e+]+)$", log, flags=re.M)
+    assert "RANDOM weights" in log
+    # every FID line of the log carries the tag, next to the value
+    top = re.findall(r"^No\.(\d+) (\[.*?\]) fid = ([-0-9.e+]+) \[FID on RANDOM Inception weights: not a quality metric\]$", log, flags=re.M)
     assert top and all(np.isfinite(float(f)) for _, _, f in top), log[-2000:]
+    assert len(top) == len(re.findall(r"^No\.\d+ .* fid = ", log, flags=re.M))
+    assert all("RANDOM Inception" in ln for ln in log.splitlines() if ln.startswith("cand: ") and ", fid: " in ln)
     return [(c, float(f)) for _, c, f in top]
 
 
@@ -88,6 +95,7 @@ def test_search_cli_with_the_bundled_inception_extractor(tmp_path):
     on one rank and with every candidate's images sharded over two ranks (features are per image, the float64 sums pooled)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    assert _run_bundled(tmp_path, "inc0", 1, opt_in=False) is None
     top1 = _run_bundled(tmp_path, "inc1", 1)
     top2 = _run_bundled(tmp_path, "inc2", 2)
     assert [c for c, _ in top1] == [c for c, _ in top2]
