@@ -188,7 +188,7 @@ linear_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w, co
   }
 }
 
-// Few rows (n <= 64: the Stable-Diffusion UNet evaluates 12 latents): a GEMV-shaped pass.  The 64 x 64 tile kernel above
+// K not a multiple of 16 (k % 4 == 0; designed for few rows): a GEMV-shaped pass.  The 64 x 64 tile kernel above
 // leaves most of its rows empty and crawls through K behind two barriers per 16-deep step; here a block keeps 16 input rows
 // (activation applied) in LDS, each wave streams whole weight rows with 16-byte lanes (every weight is read once per 16
 // rows) and reduces 16 dot products per output column across its lanes.
@@ -289,8 +289,10 @@ extern "C" int adm_linear_f32(const float* in, const float* w, const float* bias
     }
     return adm_check_launch("adm_linear_f32");
   }
-  // k not a multiple of 16 (or unaligned operands), few rows: the GEMV-shaped kernel
-  if (n <= 64 && k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
+  // k not a multiple of 16 (the attention pool's 1000-wide backward projection): the GEMV-shaped kernel at ANY row count -- a block
+  // owns 16 rows, so more rows are more blocks re-streaming the weights through L2; choosing the tile kernel from 65 rows on made
+  // the guidance gradient's bits depend on the batch size (found by tests/test_hip_bigbatch.py at batch 256 vs 2)
+  if (k % 4 == 0 && small_lds <= 128 * 1024 && adm_aligned16(w) && adm_aligned16(in)) {
     static bool attr_set[64][2] = {};  // per device: opt in to the dynamic LDS size once per instantiation
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -118,12 +118,12 @@ def _linear_path(n, k):
     row's bits never depend on the batch it rides in), GEMV-shaped, 64x64 tile."""
     if k % 16 == 0:
         return "mfma"
-    return "small" if n <= 64 and k % 4 == 0 else "tile"
+    return "small" if k % 4 == 0 else "tile"
 
 
 @pytest.mark.parametrize("n,k,o", [(2, 128, 64), (5, 768, 1000), (256, 768, 1536), (3, 32, 128), (12, 1280, 21120), (48, 1280, 333),
                                    (17, 320, 1280), (1, 4, 1), (65, 128, 96), (7, 30, 50), (70, 48, 50), (130, 16, 33),
-                                   (300, 64, 40), (129, 30, 20)])
+                                   (300, 64, 40), (129, 30, 20), (200, 1000, 512), (66, 20, 24)])
 def test_linear_f32(ops, n, k, o):
     x, w, b = rnd((n, k), 1), rnd((o, k), 2, k ** -0.5), rnd((o,), 3, 0.1)
     tab, idx = rnd((10, o), 4), torch.randint(0, 10, (n,), generator=torch.Generator().manual_seed(5))
@@ -134,7 +134,7 @@ def test_linear_f32(ops, n, k, o):
     torch.testing.assert_close(got, F.linear(x, w), rtol=1e-4, atol=1e-4)
     if n >= 4 and _linear_path(n, k) == _linear_path(n - n // 2, k):  # a row's result does not depend on where it sits in the batch (same kernel)
         assert torch.equal(ops.linear_f32(x[n // 2:].contiguous().to(DEV), w.to(DEV), None).cpu(), got[n // 2:])
-    if k % 16 == 0:   # ... nor on how many rows ride along: 2 rows alone == the first 2 of n (the matrix-pipe kernel at any n)
+    if k % 4 == 0 and n >= 2:   # ... nor on how many rows ride along: 2 rows alone == the first 2 of n (the kernel is chosen by k only)
         assert torch.equal(ops.linear_f32(x[:2].contiguous().to(DEV), w.to(DEV), None).cpu(), got[:2])
 
 
