@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")
 # the same kernels built with IEEE half as the 16-bit element type (csrc/adm_common.h, -DADM_ACT_F16): the reference's own
 # torso precision (use_fp16=True); selected per tensor dtype by ops.py, per model by `torso="fp16"` / ADM_TORSO=fp16
 LIB_PATH_F16 = os.environ.get("ADM_HIP_LIB_F16") or os.path.join(_HERE, "libadm_hip_f16.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class AdmError(RuntimeError):
@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
         ("cout", C.c_int32), ("taps", C.c_int32), ("prologue", C.c_int32), ("out_mode", C.c_int32),
         ("variant", C.c_int32), ("out_stats", C.c_void_p), ("w_packed32", C.c_void_p),
         ("in_up", C.c_int32), ("res_up", C.c_int32), ("ksplit", C.c_int32), ("ws", C.c_void_p),
-        ("up_phase", C.c_int32),
+        ("up_phase", C.c_int32), ("geglu", C.c_int32),
     ]
 
 

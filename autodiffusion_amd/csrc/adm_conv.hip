@@ -170,6 +170,13 @@ conv_kernel(const ConvK p) {
   constexpr int SEGSH = KS == 1 ? 2 : 3;   // log2(SEGP)
   constexpr int ROWB = conv_rowb(KS);      // LDS bytes per halo pixel
   constexpr int PASSES = (HALO * SEGP + NT - 1) / NT;
+  // OCC == 1: the ONE-WAVE-PER-SIMD build of the 256-pixel tile (4 waves of 128 pixels x TN * 16 channels, 512 registers each:
+  // the accumulators live in the AGPR half).  No partner wave hides anything, so the K loop is ONE software-pipelined stream per
+  // chunk (chunk1 below): every global load is consumed >= 2-3 taps after its issue, LDS fragment reads run two pixel rows ahead
+  // of their MFMAs across tap boundaries, the GroupNorm affine of a lane's 8 channels rides in registers, and the prologue
+  // VALU / load / LDS-write instructions are dealt two per MFMA gap (sched_group_barrier) instead of being fenced off
+  constexpr bool ONEW = OCC == 1;
+  static_assert(!ONEW || (TAPS == 9 && HALO == 324 && WM == 2 && WN == 2 && KS == 1), "the one-wave-per-SIMD build is the 3x3 256-pixel tile");
   constexpr bool T3 = TAPS == 9 || TAPS == 4;   // 3x3 geometry; TAPS == 4: an up-conv phase (4 of the 9 taps live)
   constexpr bool UPPH = TAPS == 4;
   constexpr int PAD = T3 ? 1 : 0;
@@ -309,7 +316,7 @@ conv_kernel(const ConvK p) {
     // a[buf][ti][KCS] followed by b[buf][ti][KCS]; each half is 2*KCS lanes x 16 B, lane-linear, so KS
     // wave-instructions move it: waves 0..KS-1 the a half, waves KS..2KS-1 the b half (32-bit offsets into
     // a descriptor over the whole [N][Cin] table)
-    if constexpr (PRO != 0) {
+    if constexpr (PRO != 0 && !ONEW) {
       if (wave < 2 * KS) {
         const int half = wave / KS, idx = (wave % KS) * 64 + lane_s;  // idx = (buf * TI_MAX + ti) * (KCS/4) + part
         const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(half == 0 ? p.aa : p.ab), 0, p.N * Cin * 4, 0x00020000);
@@ -356,16 +363,35 @@ conv_kernel(const ConvK p) {
       }
     }
   };
+  // ONEW: the affine of this lane's 8 channels (its 16-byte segment of every halo pixel) of ONE chunk, in registers: a | b,
+  // fetched straight from the [N][Cin] tables (every lane with the same segment reads the same 64 bytes: L1 / L2 hits)
+  [[maybe_unused]] float4 afr[4];
+  auto affine_regs = [&](int c, int im0) {
+    if constexpr (PRO != 0) {
+      const long long o = (long long)min(im0, p.N - 1) * Cin + c * KCS + seg * 8;
+      afr[0] = *reinterpret_cast<const float4*>(p.aa + o);
+      afr[1] = *reinterpret_cast<const float4*>(p.aa + o + 4);
+      afr[2] = *reinterpret_cast<const float4*>(p.ab + o);
+      afr[3] = *reinterpret_cast<const float4*>(p.ab + o + 4);
+    }
+  };
   // transform (fp32 affine [+ SiLU], rounded to bf16) and park a segment; zero padding stays exactly zero
   auto halo_write = [&](uint4 v, int ps, int buf) {
     if constexpr (PRO != 0) {
+      float a8[8], b8[8];
+      if constexpr (ONEW) {
+        *reinterpret_cast<float4*>(a8) = afr[0];
+        *reinterpret_cast<float4*>(a8 + 4) = afr[1];
+        *reinterpret_cast<float4*>(b8) = afr[2];
+        *reinterpret_cast<float4*>(b8 + 4) = afr[3];
+      } else {
       const int ti = (ti_pack >> (4 * ps)) & 15;
       const float* ab = abuf + (buf * TI_MAX + ti) * KCS + seg * 8;
-      float a8[8], b8[8];
       *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(ab);
       *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(ab + 4);
       *reinterpret_cast<float4*>(b8) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * KCS);
       *reinterpret_cast<float4*>(b8 + 4) = *reinterpret_cast<const float4*>(ab + 2 * TI_MAX * KCS + 4);
+      }
       uint32_t u[4] = {v.x, v.y, v.z, v.w};
       const bool valid = pixrel[ps] >= 0;
 #pragma unroll
@@ -447,6 +473,7 @@ conv_kernel(const ConvK p) {
       for (int ps = 0; ps < PASSES; ++ps) ring[2][ps] = halo_load(min(2, last), ps);
 #endif
     }
+    if constexpr (ONEW) affine_regs(cb, img0);   // first_park transforms the tile's first chunk with these
     // bias fragment (whole float4 or nothing: a ragged last fragment only exists with the fp32 NCHW output,
     // which adds those channels' bias at the store)
 #pragma unroll
@@ -484,7 +511,111 @@ conv_kernel(const ConvK p) {
 
     const int tnext = tl + gx;
     const bool more = tnext < tcount;
-    if constexpr (T3) {
+    if constexpr (T3 && ONEW) {
+      // One chunk = 9 taps x 8 pixel rows x TN MFMAs as ONE stream.  Per tap t: the weight fragments of tap t + 2 (ring of 3), then
+      // (taps 0-2) two of the six raw halo passes of chunk c + 1 -- issued behind the weights, so that the in-order vmcnt wait for
+      // the next tap's weights never drains them --, at tap 0 the next chunk's affine registers; the pass fetched at tap q / 2 is
+      // transformed and parked at tap q + 3 (>= 3 taps = ~2300 cycles after its issue).  Fragment row R = 8 t + i is read from LDS
+      // two rows (12 MFMAs) ahead of its MFMAs, across tap boundaries; only rows 0 and 1 of a chunk wait for their reads (the
+      // other halo buffer becomes readable at the chunk's barrier).
+      constexpr int HW2C = 18;                                   // halo row of the 16 x 16 patch (host: TW == TH == 16)
+      const unsigned char* const hl0 = halo + alane + aoff[0];   // this lane's fragment row 0 in halo buffer 0
+      // The stream is HAND-PLACED: one scheduling region per MFMA (sched_barrier after every slot), each holding that MFMA and
+      // at most a few staging instructions chosen here -- hipcc's own placement of the same work bunched the ~65 VALU
+      // instructions of a pass transform into two pixel rows and sank every fragment read next to its use.
+      //   slot (i, 0)       the LDS read of fragment row R + 2 precedes it
+      //   slot (i, 1)       i < TN: weight fragment i of tap t + 2;  i = 6, 7 at taps 0-2: a raw halo pass of chunk c + 1
+      //   slots (i, >= 2)   taps 3-8: the transform of pass t - 3, as 64 "pair-ops" (4 channel pairs x 16 dependent single
+      //                     instructions: unpack, fma, -log2e, exp2, +1, rcp, multiply, pack, zero-pad select), two pairs
+      //                     interleaved so that consecutive instructions of one chain sit one MFMA apart;  (7, TN-1): the LDS write
+      auto chunk1 = [&](int c, auto more_) {
+        constexpr bool MORE = decltype(more_)::value;
+        constexpr int NSLOT = 8 * (TN - 2), OPS = 64 / NSLOT;    // transform slots per tap, pair-ops per slot
+        static_assert(TN >= 3 && 64 % NSLOT == 0, "chunk1: TN - 2 transform slots per pixel row");
+        const int hb = c & 1;
+        const int step0 = c * 9;
+        const unsigned char* const hl = hl0 + hb * Lds::HB;
+        [[maybe_unused]] uint4 hr[PASSES];
+        [[maybe_unused]] float xl[4], xh[4], el[4], eh[4];
+        adm_h8 af[3];
+        auto rd = [&](int R) -> adm_h8 {   // R = 8 t + i (compile-time in the unrolled stream)
+          const int t = R >> 3, i = R & 7;
+          return *reinterpret_cast<const adm_h8*>(hl + (((t / 3) * HW2C + (t % 3)) + i * HW2C) * ROWB);
+        };
+        auto comp = [](uint4& v, int k) -> uint32_t& { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); };
+        auto xop = [&](uint4& v, int pr, int op, int ps) {   // pair pr (channels 2 pr, 2 pr + 1 of the lane's segment), instruction op
+          uint32_t& u = comp(v, pr);
+          const float4 av = afr[pr >> 1], bv = afr[2 + (pr >> 1)];
+          const float a_lo = (pr & 1) ? av.z : av.x, a_hi = (pr & 1) ? av.w : av.y;
+          const float b_lo = (pr & 1) ? bv.z : bv.x, b_hi = (pr & 1) ? bv.w : bv.y;
+          switch (op) {
+            case 0: xl[pr] = adm_lo_f32(u); break;
+            case 1: xh[pr] = adm_hi_f32(u); break;
+            case 2: xl[pr] = __builtin_fmaf(a_lo, xl[pr], b_lo); break;
+            case 3: xh[pr] = __builtin_fmaf(a_hi, xh[pr], b_hi); break;
+            case 4: if (PRO == 2) el[pr] = xl[pr] * -1.4426950408889634f; break;
+            case 5: if (PRO == 2) eh[pr] = xh[pr] * -1.4426950408889634f; break;
+            case 6: if (PRO == 2) el[pr] = __builtin_amdgcn_exp2f(el[pr]); break;
+            case 7: if (PRO == 2) eh[pr] = __builtin_amdgcn_exp2f(eh[pr]); break;
+            case 8: if (PRO == 2) el[pr] = el[pr] + 1.0f; break;
+            case 9: if (PRO == 2) eh[pr] = eh[pr] + 1.0f; break;
+            case 10: if (PRO == 2) el[pr] = __builtin_amdgcn_rcpf(el[pr]); break;
+            case 11: if (PRO == 2) eh[pr] = __builtin_amdgcn_rcpf(eh[pr]); break;
+            case 12: if (PRO == 2) xl[pr] = xl[pr] * el[pr]; break;
+            case 13: if (PRO == 2) xh[pr] = xh[pr] * eh[pr]; break;
+            case 14: u = adm_pack2(xl[pr], xh[pr]); break;
+            default: u = pixrel[ps] >= 0 ? u : 0u; break;   // zero padding stays exactly zero
+          }
+          // pin the instruction into THIS slot: pure arithmetic is otherwise free to move across the sched_barrier fences before
+          // instruction selection (hipcc sank whole dependent chains next to their last use); an empty volatile asm that reads
+          // and writes the value orders it with the fences at no cost
+          if (op == 0 || op == 2 || op == 12) asm volatile("" : "+v"(xl[pr]));
+          else if (op == 1 || op == 3 || op == 13) asm volatile("" : "+v"(xh[pr]));
+          else if (op >= 14) asm volatile("" : "+v"(u));
+          else if (PRO == 2 && !(op & 1)) asm volatile("" : "+v"(el[pr]));
+          else if (PRO == 2) asm volatile("" : "+v"(eh[pr]));
+        };
+        af[0] = rd(0);
+        af[1] = rd(1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int R = t * 8 + i;
+            if (R + 2 < 72) af[(R + 2) % 3] = rd(R + 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              acc[i][j] = adm_mfma_16x16x32(__builtin_bit_cast(adm_h8, wr[t % 3][j]), af[R % 3], acc[i][j], 0, 0, 0);
+              if (j == 1) {
+                if (i < TN && (MORE || t + 2 < 9)) wr[(t + 2) % 3][i] = bufload16(rsw, wofs[i], (unsigned)(step0 + t + 2) * wstep);
+                if constexpr (MORE) {
+                  if (t < 3 && i >= 6 && 2 * t + (i - 6) < PASSES) hr[2 * t + (i - 6)] = halo_load(c + 1, 2 * t + (i - 6));
+                }
+              }
+              if constexpr (MORE) {
+                if (PRO != 0 && t == 0 && i == 7 && j == 2) affine_regs(c + 1, img0);   // read by the transforms of taps 3-8
+                if (t >= 3 && t - 3 < PASSES) {
+                  if (PRO != 0 && j >= 2) {
+#pragma unroll
+                    for (int q = 0; q < OPS; ++q) {
+                      const int m = (i * (TN - 2) + (j - 2)) * OPS + q;    // pair-op 0..63
+                      xop(hr[t - 3], (m & 1) + 2 * (m >> 5), (m & 31) >> 1, t - 3);
+                    }
+                  }
+                  if (i == TM - 1 && j == TN - 1)
+                    *reinterpret_cast<uint4*>(halo + (hb ^ 1) * Lds::HB + (t - 3) * (NT / SEGP) * ROWB + hslot) = hr[t - 3];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        __syncthreads();  // halo[hb^1] complete; every wave is done reading halo[hb]
+      };
+      static_assert(PASSES <= 6, "chunk1 fetches two halo passes per tap over taps 0-2");
+      for (int c = cb; c + 1 < ce; ++c) chunk1(c, std::true_type{});
+      chunk1(ce - 1, std::false_type{});
+    } else if constexpr (T3) {
       // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
       auto chunk = [&](int c, auto more_) {
         constexpr bool MORE = decltype(more_)::value;
@@ -1398,6 +1529,8 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
 
   // 1x1 with the activation tile resident in LDS across all Cout blocks (adm_conv1x1.hip)
   if (adm_conv1x1_resident_cfg(a, nullptr)) return adm_conv1x1_resident_launch(a, stream);
+  ADM_REQUIRE(!a->geglu, ADM_E_SHAPE, "adm_conv: geglu needs a 1x1 conv the resident-tile kernel takes (raw input, no residual / statistics, "
+              "(c0 + c1) %% 64 == 0, cout %% 16 == 0, cout > 192, h * w %% 64 == 0, the pixel tile x all input channels within 160 KB of LDS)");
   ADM_REQUIRE(a->variant != 10, ADM_E_SHAPE, "adm_conv: variant 10 (resident-tile 1x1) does not take this shape");
 
   ConvK k{};
@@ -1455,7 +1588,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     k.res = nullptr;      // bias, residual and statistics belong to the reduce pass
     k.stats = nullptr;
   }
-  ADM_REQUIRE(!(k.in_up || k.res_up || a->up_phase) || variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: in_up / res_up / up_phase need tiling variant 5 or 6");
+  ADM_REQUIRE(!(k.in_up || k.res_up || a->up_phase) || variant == 5 || variant == 6 || (variant == 8 && !a->up_phase), ADM_E_ARG, "adm_conv: in_up / res_up / up_phase need tiling variant 5 or 6");
   if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
     ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out");
     ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1, ADM_E_SHAPE, "adm_conv: variant 7 needs maps >= 16x16");
@@ -1470,6 +1603,15 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   }
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
   const bool small_map = a->h * a->w <= 64;
+  if (variant == 8) {
+    // structural experiment (explicit only): the 256-pixel x 192-channel tile on FOUR waves, one per SIMD, each 128 pixels x
+    // 96 channels (8 x 6 MFMA tiles = 192 accumulator registers of a 512-register wave): half the LDS fragment reads and half
+    // the weight-fragment loads per MFMA of the 8-wave tile, and registers to spare for the tile switch
+    ADM_REQUIRE(a->taps == 9 && !small_map && a->out_mode == 0 && k.ksplit <= 1 && !a->up_phase && a->prologue != 3, ADM_E_ARG,
+                "adm_conv: variant 8 takes 3x3 convs with bf16 output on maps >= 16x16");
+    ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1 && k.TW == 16 && k.TH == 16, ADM_E_SHAPE, "adm_conv: variant 8 needs maps >= 16x16");
+    return launch_conv<2, 2, 8, 6, 1, 9, 324, 1>(k, a->prologue, k.N * k.tiles_x * k.tiles_y, s);
+  }
   if (k.ksplit > 1) {
     int rc;
     if (variant == 5) rc = small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, 9, a->prologue, s);

@@ -60,7 +60,11 @@ constexpr int c1_lds_bytes(int k) { return BM * (2 * k + 32) + c1_stg_bytes<BM>(
 // WP: wave-private barrier-free epilogue (outputs without a residual operand) or the block-wide two-half epilogue
 // WM: 1 = waves 1 x 8 (block BM x 384 channels, a wave owns all BM pixels); 2 = waves 2 x 4 (block BM x 192, a wave
 //     owns half the pixels: outputs no wider than 192 channels)
-template <int BM, int PRO, bool WP, int WM>
+// GG: GEGLU epilogue (adm_conv_args.geglu; WP, WM = 1 only): the projection's output channels arrive INTERLEAVED (row 2m = value m,
+//     row 2m + 1 = gate m: the host packs the weight and the bias that way), so a lane's four consecutive accumulator channels are
+//     two (value, gate) pairs and out[pixel][m] = value_m * gelu(gate_m) is formed in registers from the fp32 accumulators: the
+//     [pixels][2 * inner] tensor is never written (SD: ldm/modules/attention.py:37-44, GEGLU.forward)
+template <int BM, int PRO, bool WP, int WM, bool GG = false>
 __global__ void __launch_bounds__(512, 2)
 conv1x1r_kernel(const Conv1K p) {
   constexpr int NT = 512, WN = 8 / WM, BN = WN * 48, TM = BM / 16 / WM, TN = 3, BNH = 192;   // BNH: channels per block-epilogue half (4 waves x 48)
@@ -202,7 +206,36 @@ conv1x1r_kernel(const Conv1K p) {
       if (k0 + 1 <= last) kstep(k0 + 1, wr[1]);
       if (k0 + 2 <= last) kstep(k0 + 2, wr[2]);
 
-      if constexpr (WP) {
+      if constexpr (GG) {
+      // ---- GEGLU epilogue, wave-private and barrier-free like the one below: 48 accumulator channels = 24 output channels per wave;
+      // restaged 32 pixels at a time as 48-byte rows (64-byte pitch) in the wave's private LDS, stored as 16-byte segments
+      const int cbw = nb * BN + wn * 48;
+      if (cbw < p.Cout) {                               // wave-uniform
+        unsigned char* const wst = stg + wave * WST;
+        const int Co = p.Cout >> 1, cbo = cbw >> 1;
+        const int sgl = lane % 3, rowl = lane / 3;      // lanes 0..62: segment sgl of pixel row rowl (+21)
+        const bool lact = lane < 63 && cbo + sgl * 8 < Co;
+#pragma unroll
+        for (int c = 0; c < TM / 2; ++c) {              // 32 pixels per round
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const f32x4 v = acc[2 * c + ii][j];       // (value, gate, value, gate)
+              const float y0 = v[0] * (0.5f * v[1] * (1.0f + erff(v[1] * 0.70710678118654752f)));
+              const float y1 = v[2] * (0.5f * v[3] * (1.0f + erff(v[3] * 0.70710678118654752f)));
+              *reinterpret_cast<uint32_t*>(wst + (ii * 16 + lc) * 64 + (j * 8 + lq * 2) * 2) = adm_pack2(y0, y1);
+            }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {                 // rows rowl, +21 (< 32)
+            const int r = rowl + q * 21;
+            if (!lact || r >= 32) continue;
+            const long long eo = ((long long)pb + c * 32 + r) * Co + cbo + sgl * 8;
+            *reinterpret_cast<uint4*>(p.out + eo) = *reinterpret_cast<const uint4*>(wst + r * 64 + sgl * 16);
+          }
+        }
+      }
+      } else if constexpr (WP) {
       // ---- epilogue, WAVE-PRIVATE and barrier-free: a wave owns all BM pixels of its 48 channels, so it restages
       // its own accumulators (32 pixels at a time, bf16, 112-byte rows in its private 4 KB of LDS), reads them back
       // as 16-byte row segments (6 per pixel, 10 pixels per wave-instruction) and stores them, adding the residual
@@ -363,13 +396,13 @@ conv1x1r_kernel(const Conv1K p) {
   }
 }
 
-template <int BM, int PRO, bool WP, int WM>
+template <int BM, int PRO, bool WP, int WM, bool GG = false>
 int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
   static int slots_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   int& slots = slots_dev[dev & 63];
-  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO, WP, WM>);
+  const void* fn = reinterpret_cast<const void*>(&conv1x1r_kernel<BM, PRO, WP, WM, GG>);
   if (slots == 0) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv (1x1 resident): hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -379,7 +412,7 @@ int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
     slots = ncu;  // one block per CU: the resident tile takes most of the LDS
   }
   const unsigned blocks = (unsigned)(k.m_tiles < slots ? k.m_tiles : slots);
-  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO, WP, WM>), dim3(blocks), dim3(512), smem, s, k);
+  hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO, WP, WM, GG>), dim3(blocks), dim3(512), smem, s, k);
   return adm_check_launch("adm_conv");
 }
 
@@ -396,6 +429,7 @@ int adm_conv1x1_resident_cfg(const adm_conv_args* a, int* wm_out) {
   // narrow outputs: the 2 x 4 wave layout measured no faster than the staged kernel (its K loop is weight-load bound
   // at 12 MFMAs per 3 fragment loads), so the automatic choice leaves them there; variant 10 still takes them
   if (a->variant == 0 && a->cout < 256) return 0;
+  if (a->geglu && (a->res || a->out_stats || a->prologue != 0 || a->cout % 16 != 0 || a->cout <= 192)) return 0;
   if (wm_out) *wm_out = a->cout <= 192 ? 2 : 1;
   const int lim = 160 * 1024;
   if (hw % 128 == 0 && c1_lds_bytes<128>(k) <= lim) return 128;
@@ -437,6 +471,8 @@ int adm_conv1x1_resident_launch(const adm_conv_args* a, void* stream) {
   k.rcp_seg = (unsigned)(((1ull << 32) + segk - 1) / segk);
   hipStream_t s = (hipStream_t)stream;
   const int smem = bm == 128 ? c1_lds_bytes<128>(kk) : c1_lds_bytes<64>(kk);
+  if (a->geglu)   // raw input, no residual, no statistics, 384-wide Cout blocks (checked by adm_conv1x1_resident_cfg)
+    return bm == 128 ? launch_c1<128, 0, true, 1, true>(k, smem, s) : launch_c1<64, 0, true, 1, true>(k, smem, s);
   if (bm == 128) return wm == 1 ? launch_c1_cfg<128, 1>(a, k, smem, s) : launch_c1_cfg<128, 2>(a, k, smem, s);
   return wm == 1 ? launch_c1_cfg<64, 1>(a, k, smem, s) : launch_c1_cfg<64, 2>(a, k, smem, s);
 }

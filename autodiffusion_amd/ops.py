@@ -284,7 +284,7 @@ def splitk_for(h: int, w: int, cin: int) -> int:
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
          out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1,
-         w_up=None, gnb=None):
+         w_up=None, gnb=None, geglu=False):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): 16-bit NHWC (bf16, or fp16 for an fp16-torso model: the library is picked by x0's dtype).  Returns the same
@@ -292,6 +292,8 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     in_up / res_up: x0 / res are at half resolution and are read through a virtual nearest-neighbour 2x upsample
     (the output is [n, 2h, 2w, cout]): ResBlock(up=True) without materialising the upsampled tensors.  With w_up
     (pack_conv_weight_up) an in_up conv runs as four phase launches of 2x2 live taps each (4/9 of the MACs).
+    geglu: w_packed / bias are an interleaved (value, gate) projection (geglu_interleave); returns [n, h, w, cout // 2] =
+    value * gelu(gate) -- the Stable-Diffusion GEGLU without the [.., cout] tensor (1x1 resident-tile kernel only).
     """
     n, h, w, c0 = x0.shape
     if (in_up and w_up is not None and UPCONV_PHASES and taps == 9 and x1 is None and res is None and not res_up
@@ -301,10 +303,13 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
         h, w = 2 * h, 2 * w
     c1 = 0 if x1 is None else x1.shape[3]
     dev = x0.device
+    if geglu and (taps != 1 or res is not None or aff is not None or want_stats or out_f32_nchw or gnb is not None or ksplit > 1):
+        raise AdmError("conv(geglu=True): a raw 1x1 projection without residual / statistics")
     if out is None:
         out = (torch.empty((n, cout, h, w), dtype=torch.float32, device=dev) if out_f32_nchw
-               else torch.empty((n, h, w, cout), dtype=x0.dtype, device=dev))
+               else torch.empty((n, h, w, cout // 2 if geglu else cout), dtype=x0.dtype, device=dev))
     a = ConvArgs()
+    a.geglu = int(bool(geglu))
     lib = _L(x0)
     a.in0, a.in1 = _ptr(x0, x0.dtype, "x0"), _ptr(x1, x0.dtype, "x1")
     a.w_packed, a.bias = _ptr(w_packed, x0.dtype, "w_packed"), _ptr(bias, torch.float32, "bias")
@@ -439,6 +444,15 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
     check(_L(x).adm_layernorm(_ptr(x, x.dtype, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
                                     _ptr(out), x.numel() // c, c, float(eps), _stream()), "adm_layernorm")
     return out
+
+
+def geglu_interleave(w, b):
+    """GEGLU projection [2*I, C] / [2*I] (rows: values, then gates -- `proj(x).chunk(2, dim=-1)`) -> the row order conv(geglu=True)
+    expects: row 2m = value m, row 2m + 1 = gate m.  Pure tensor algebra (testable without a GPU)."""
+    inner = w.shape[0] // 2
+    wi = torch.stack([w[:inner], w[inner:]], dim=1).reshape(w.shape)
+    bi = torch.stack([b[:inner], b[inner:]], dim=1).reshape(b.shape)
+    return wi.contiguous(), bi.contiguous()
 
 
 def geglu(u):

@@ -153,6 +153,9 @@ class UNetModel(HipModule):
                     L["o2b"] = f32(f"{q}.attn2.to_out.0.bias")
                     L["ff1"] = pack(P[f"{q}.ff.net.0.proj.weight"])
                     L["ff1b"] = f32(f"{q}.ff.net.0.proj.bias")
+                    if b.inner <= 640:   # GEGLU in the projection's epilogue: (value, gate) rows interleaved (the resident-tile 1x1
+                        wi, bi = ops.geglu_interleave(P[f"{q}.ff.net.0.proj.weight"], P[f"{q}.ff.net.0.proj.bias"])   # kernel holds
+                        L["ff1g"], L["ff1gb"] = pack(wi), bi.to(torch.float32).contiguous()   # <= 640 input channels per 64-pixel tile)
                     L["ff2"] = pack(P[f"{q}.ff.net.2.weight"])
                     L["ff2b"] = f32(f"{q}.ff.net.2.bias")
                     d["layers"].append(L)
@@ -208,8 +211,11 @@ class UNetModel(HipModule):
             h = ops.conv(a.view(n, hh, ww, hd), L["o2"], L["o2b"], inner, 1, res=h)
             # gated feed-forward
             y = ops.layernorm(h, *L["norm3"])
-            u = ops.conv(y, L["ff1"], L["ff1b"], 8 * inner, 1)
-            h = ops.conv(ops.geglu(u), L["ff2"], L["ff2b"], inner, 1, res=h)
+            if self.fuse_geglu and "ff1g" in L and t % 64 == 0:
+                gl = ops.conv(y, L["ff1g"], L["ff1gb"], 8 * inner, 1, geglu=True)    # [n, hh, ww, 4 * inner]: u never exists
+            else:
+                gl = ops.geglu(ops.conv(y, L["ff1"], L["ff1b"], 8 * inner, 1))
+            h = ops.conv(gl, L["ff2"], L["ff2b"], inner, 1, res=h)
         return ops.conv(h, d["w_out"], d["b_out"], c, 1, res=x, want_stats=True)
 
     def _run_seq(self, pr, seq, h, skip, emb, kvs, n_ctx, x_nchw=None):
@@ -240,6 +246,7 @@ class UNetModel(HipModule):
     # ------------------------------------------------------------------ forward
     use_graph = False  # replay one captured hipGraph per input shape (set by .enable_graph())
 
+    fuse_geglu = os.environ.get("ADM_SD_FUSE_GEGLU", "1") != "0"   # GEGLU in the C -> 8C projection's epilogue (per model, never by batch)
     small_batch_splitk = False  # split the K loop of the 8x8 / 16x16-level 3x3 convs (set by .enable_splitk())
     upconv_phases = ops.UPCONV_PHASES   # Upsample convs as four 2x2-tap phase convs (a per-model choice, never by batch)
 
@@ -328,7 +335,7 @@ class UNetModel(HipModule):
         # stream serialise by stream order.
         # the launch-sequence switches are part of the key: toggling one after the first replay must not keep the old capture
         key = (tuple(x.shape), x.dtype, tuple(timesteps.shape), timesteps.dtype, tuple(context.shape),
-               torch.cuda.current_stream(x.device).cuda_stream, self.small_batch_splitk, self.upconv_phases)
+               torch.cuda.current_stream(x.device).cuda_stream, self.small_batch_splitk, self.upconv_phases, self.fuse_geglu)
         entry = pr.graphs.get(key)
         if entry is None:
             sx, st = x.clone(), timesteps.clone()

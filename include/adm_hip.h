@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 5   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase */
+#define ADM_ABI_VERSION 6   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -177,6 +177,11 @@ typedef struct adm_conv_args {
                         back to back (phase-major) and the phase is part of the tile index (4 x as many tiles: small batches
                         still fill the chip).  out_stats has adm_conv_stat_slabs = 4 x (h / 16) x (w / 16) slabs, one per
                         (source tile, phase).  3x3, bf16 output, c1 == 0, no residual, source >= 16x16, variant 0/5/6            */
+  int32_t geglu;     /* 1: GEGLU epilogue (Stable-Diffusion feed-forward, ldm/modules/attention.py:37-44: `x, gate = proj(x).chunk(2);
+                        return x * gelu(gate)`): w_packed / bias hold the projection with its output rows INTERLEAVED (row 2m = value
+                        m = reference row m, row 2m + 1 = gate m = reference row cout/2 + m), and `out` is [n][h][w][cout / 2] =
+                        value * gelu(gate) (exact erf GELU on the fp32 accumulators): the [.., cout] tensor is never written.  1x1 on the
+                        resident-tile kernel only: raw input, no res / out_stats, cout %% 16 == 0, cout > 192                      */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

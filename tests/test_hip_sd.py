@@ -56,6 +56,35 @@ def test_geglu(rows, inner):
     check(ops.geglu(u), (a * F.gelu(gate)).cpu(), f"geglu {rows}x{inner}", 5e-3, 2e-2)
 
 
+@pytest.mark.parametrize("n,hw,c,dtype", [(2, 32, 320, torch.bfloat16), (1, 64, 320, torch.float16), (3, 16, 640, torch.bfloat16),
+                                          (1, 8, 384, torch.bfloat16), (2, 8, 64, torch.float16)])
+def test_geglu_in_the_projection_epilogue(n, hw, c, dtype):
+    """conv(geglu=True): the GEGLU feed-forward's `proj(x).chunk(2)` -> x * gelu(gate) (SD/ldm/modules/attention.py:37-44) formed in
+    the 1x1 projection's epilogue from interleaved (value, gate) weight rows, against PyTorch fp32 on the same 16-bit operands; the
+    fused form is closer to it than projection -> 16-bit tensor -> adm_geglu (the gate is not rounded in between)."""
+    from autodiffusion_amd import ops
+    g = torch.Generator().manual_seed(hw + c)
+    inner = 4 * c
+    x = (torch.randn(n, hw, hw, c, generator=g)).to(dtype).to(DEV)
+    w = torch.randn(2 * inner, c, generator=g) * c ** -0.5 * 1.5
+    b = 0.1 * torch.randn(2 * inner, generator=g)
+    wq = w.to(dtype).float()
+    u = F.linear(x.float().cpu(), wq, b)
+    val, gate = u.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    wi, bi = ops.geglu_interleave(w, b)
+    got = ops.conv(x, ops.pack_conv_weight(wi.to(DEV), dtype), bi.to(DEV), 2 * inner, 1, geglu=True)
+    assert got.shape == (n, hw, hw, inner) and got.dtype == dtype
+    check(got, ref, f"fused geglu {n}x{hw}x{hw}x{c}", 4e-3, 2e-2)
+    two = ops.geglu(ops.conv(x, ops.pack_conv_weight(w.to(DEV), dtype), b.to(DEV), 2 * inner, 1))
+    check(two, ref, f"two-pass geglu {n}x{hw}x{hw}x{c}", 8e-3, 3e-2)
+    e1, e2 = float((got.float().cpu() - ref).norm()), float((two.float().cpu() - ref).norm())
+    assert e1 <= e2 * 1.05, (e1, e2)
+    from autodiffusion_amd._lib import AdmError
+    with pytest.raises(AdmError):   # not a shape the resident-tile kernel takes: refused, never silently unfused
+        ops.conv(x[:, :, :, :32].contiguous(), ops.pack_conv_weight(wi[:, :32].contiguous().to(DEV), dtype), bi.to(DEV), 2 * inner, 1, geglu=True)
+
+
 @pytest.mark.parametrize("n,tq,tk,rows,heads,d,true_d", [
     (2, 256, 77, 128, 8, 64, 40),     # cross-attention of the 320-channel level (40-wide heads padded to 64)
     (1, 1024, 77, 128, 8, 128, 80),

@@ -163,3 +163,17 @@ def test_sd_unet_module_surface_on_the_cpu():
     with pytest.raises(NotImplementedError):
         UNetModel(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[1],
                   num_heads=2, use_spatial_transformer=False, context_dim=None)
+
+
+def test_geglu_interleave_is_the_chunk2_reordering():
+    """ops.geglu_interleave: rows (values | gates) of the GEGLU projection -> (value m, gate m) pairs; value * gelu(gate) of the
+    de-interleaved product equals the reference's `x, gate = proj(x).chunk(2, dim=-1)` form."""
+    import torch.nn.functional as F
+    from autodiffusion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w, b, x = torch.randn(24, 5, generator=g), torch.randn(24, generator=g), torch.randn(7, 5, generator=g)
+    wi, bi = ops.geglu_interleave(w, b)
+    assert torch.equal(wi[0::2], w[:12]) and torch.equal(wi[1::2], w[12:]) and torch.equal(bi[0::2], b[:12]) and torch.equal(bi[1::2], b[12:])
+    val, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ui = F.linear(x, wi, bi)
+    torch.testing.assert_close(ui[:, 0::2] * F.gelu(ui[:, 1::2]), val * F.gelu(gate), rtol=1e-6, atol=1e-6)
