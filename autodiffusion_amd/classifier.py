@@ -32,6 +32,18 @@ class EncoderUNetModel(AdmNet):
             raise ValueError("EncoderUNetModel needs an encoder plan with the attention pool head")
         super().__init__(plan, use_fp16)
 
+    # The backward-data network's tensors are tiny: d(logits) <= 1, and 40 layers later the medians sit at 4e-6 .. 5e-4, with up to
+    # 100 % of a tensor's elements below fp16's smallest normal (6.1e-5; tools/mixed_torso_probe.py, profiles/r03/mixed_torso_probe.log).
+    # bf16 has fp32's exponent range and needs nothing.  With an fp16 torso (set_torso("fp16"): 11 mantissa bits, the guidance
+    # gradient's error against the reference's autograd 2.0e-2 -> 4e-3) the whole chain is LINEAR in d(logits), so it runs on
+    # d(logits) * 2^10 -- every tensor back in the normal range, max |g| * 2^10 ~ 3, far from 65504 -- and 2^-10 is folded into the
+    # weights of the last backward conv (the stem's, AdmNet._prepare): exact, no extra pass, no dynamic loss-scale state.
+    FP16_GRAD_SCALE = 1024.0
+
+    @property
+    def grad_scale(self):
+        return self.FP16_GRAD_SCALE if self.compute_dtype == torch.float16 else 1.0
+
     # ------------------------------------------------------------------ head weights
     def _prepare_head(self, pr, P, f32):
         h: AttnPoolSpec = self.plan.head
@@ -172,7 +184,7 @@ class EncoderUNetModel(AdmNet):
     def _log_prob_grad(self, x, timesteps, y, scale):
         logits, tape = self._forward_tape(x, timesteps)
         with torch.no_grad():
-            dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale)
+            dl = ops.logsoftmax_grad(logits, y.to(torch.int64).contiguous(), scale * self.grad_scale)
         return self._backward_tape(tape, dl), logits
 
 
@@ -197,5 +209,8 @@ class _ClassifierFn(torch.autograd.Function):
         tape, ctx.tape = ctx.tape, None  # one backward per forward, like a graph without retain_graph
         if tape is None:
             raise RuntimeError("the HIP classifier's activations were already released (backward called twice)")
-        g = ctx.net._backward_tape(tape, dlogits.detach().to(torch.float32).contiguous())
+        dl = dlogits.detach().to(torch.float32)
+        if ctx.net.grad_scale != 1.0:
+            dl = dl * ctx.net.grad_scale     # undone inside the network (the stem's backward weights carry 1 / grad_scale)
+        g = ctx.net._backward_tape(tape, dl.contiguous())
         return g.to(ctx.x_dtype), None, None

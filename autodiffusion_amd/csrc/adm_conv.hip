@@ -151,7 +151,11 @@ __device__ __forceinline__ uint4 bufload16(__amdgpu_buffer_rsrc_t r, unsigned vo
 // dependent latencies) or the block launch gap; here the NEXT tile's first loads are issued before the
 // current tile's accumulators are staged and stored, and land in LDS (halo buffer 0, which the output
 // staging does not overlay) while the epilogue runs.
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PROX, int KS>
+// COLD: the build also carries the two rare epilogues (split-K partial sums; fp32 NCHW output).  They are separate instantiations
+// because their tile-invariant address math is hoisted out of the tile loop and then sits in registers ACROSS the K loop of every
+// launch, used or not: without them the dominant instantiation goes from 28 spilled registers to 2 and the 128-wide tile from 224
+// to 192 registers (hipcc -Rpass-analysis=kernel-resource-usage).
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PROX, int KS, bool COLD>
 __global__ void __launch_bounds__(64 * WM * WN, OCC)
 conv_kernel(const ConvK p) {
   // PROX 0..2 = the prologue; 3 = a raw input (backward-data conv) whose EPILOGUE is the first half of the GroupNorm(+SiLU)
@@ -738,7 +742,7 @@ conv_kernel(const ConvK p) {
     // ---- tile switch.  Every wave is behind the K loop's last barrier: both halo buffers and abuf are free.
     const int ltile_done = ltile;
     (void)ltile_done;
-    if (p.out_mode == 0 && p.ksplit <= 1) {
+    if (!COLD || (p.out_mode == 0 && p.ksplit <= 1)) {
       // bf16 NHWC: the whole tile (acc + bias, bf16) is staged in LDS in ONE round and leaves as whole pixel
       // rows with 16-byte lanes (BN*2 contiguous bytes per pixel); the residual operand is fetched with the
       // same coalesced shape before the staging barrier, so that its latency overlaps the LDS round trip.
@@ -919,6 +923,8 @@ conv_kernel(const ConvK p) {
         }
       }
       ADM_TSTAMP(ltile_done, 6);
+    } else if constexpr (!COLD) {
+      // (not in this build: adm_conv sends split-K and fp32 NCHW launches to the COLD instantiations)
     } else if (p.ksplit > 1) {
       // split-K partial sums: fp32 [split][pixel][Cout], 16 bytes per lane (4 consecutive channels of one pixel)
 #pragma unroll
@@ -1325,7 +1331,7 @@ conv_splitk_reduce(const float* __restrict__ ws, int ksplit, const float* __rest
   }
 }
 
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO, int KS>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int PRO, int KS, bool COLD>
 int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BN = WN * TN * 16;
@@ -1336,7 +1342,7 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   int& slots = slots_dev[dev & 63];
-  const void* fn = reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS>);
+  const void* fn = reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS, COLD>);
   if (slots == 0) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -1358,19 +1364,19 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   // diagnostic build only: cap the persistent grid (how long is a tile's epilogue when few CUs share the HBM?)
   if (const char* e = getenv("ADM_CONV_MAX_BLOCKS")) { const unsigned cap = (unsigned)atoi(e); if (cap > 0 && cap < blocks) blocks = cap; }
 #endif
-  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS>), dim3(blocks), dim3(NT), smem, s, kk);
+  hipLaunchKernelGGL((conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS, COLD>), dim3(blocks), dim3(NT), smem, s, kk);
   return adm_check_launch("adm_conv");
 }
 
-template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int KS>
+template <int WM, int WN, int TM, int TN, int OCC, int TAPS, int HALO, int KS, bool COLD>
 int launch_conv(const ConvK& k, int prologue, int m_tiles, hipStream_t s) {
   switch (prologue) {
-    case 0: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 0, KS>(k, m_tiles, s);
-    case 1: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 1, KS>(k, m_tiles, s);
+    case 0: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 0, KS, COLD>(k, m_tiles, s);
+    case 1: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 1, KS, COLD>(k, m_tiles, s);
     case 3:   // GroupNorm-backward epilogue: 3x3 backward-data convs on the 256-pixel 8-wave tiles only
-      if constexpr (TAPS == 9 && HALO == 324 && WN == 4) return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 3, KS>(k, m_tiles, s);
+      if constexpr (TAPS == 9 && HALO == 324 && WN == 4 && !COLD) return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 3, KS, COLD>(k, m_tiles, s);
       else ADM_FAIL(ADM_E_SHAPE, "adm_conv: prologue 3 (GroupNorm-backward epilogue) needs a 3x3 conv on a map >= 16x16");
-    default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2, KS>(k, m_tiles, s);
+    default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2, KS, COLD>(k, m_tiles, s);
   }
 }
 
@@ -1393,7 +1399,7 @@ bool conv_geometry(ConvK& k, int BM, int taps, int halo_max) {
   return true;
 }
 
-template <int WM, int WN, int TM, int TN, int OCC>
+template <int WM, int WN, int TM, int TN, int OCC, bool COLD = false>
 int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
   constexpr int BM = WM * TM * 16;
   // halo capacity: one (TH+2)(TW+2) patch of one image for the 256-pixel tiles (maps >= 16x16); TI whole images
@@ -1403,22 +1409,24 @@ int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
       if (conv_geometry(k, BM, 9, 324) && k.TI == 1) {
         const int m_tiles = k.N * k.tiles_x * k.tiles_y;
         if constexpr (WN == 4) {   // up-conv phase launches exist for the 8-wave tilings only
-          if (k.tap_mask != 0x1ff) return launch_conv<WM, WN, TM, TN, OCC, 4, 324, 1>(k, prologue, m_tiles, s);
+          if constexpr (!COLD) {
+            if (k.tap_mask != 0x1ff) return launch_conv<WM, WN, TM, TN, OCC, 4, 324, 1, false>(k, prologue, m_tiles, s);
+          }
         }
-        return launch_conv<WM, WN, TM, TN, OCC, 9, 324, 1>(k, prologue, m_tiles, s);
+        return launch_conv<WM, WN, TM, TN, OCC, 9, 324, 1, COLD>(k, prologue, m_tiles, s);
       }
     } else {
       if (conv_geometry(k, BM, 9, 200)) {
         const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
-        return launch_conv<WM, WN, TM, TN, OCC, 9, 200, 1>(k, prologue, m_tiles, s);
+        return launch_conv<WM, WN, TM, TN, OCC, 9, 200, 1, COLD>(k, prologue, m_tiles, s);
       }
     }
-  } else {
+  } else if constexpr (!COLD || WN == 1) {   // 1x1: never split-K; fp32 NCHW output only on the 16-wide tile
     if (conv_geometry(k, BM, 1, BM)) {
       const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
       // 64-channel stages (two K-steps per barrier) when neither source straddles a stage
-      if (ADM_CONV_KS2 && k.C0 % 64 == 0 && k.C1 % 64 == 0) return launch_conv<WM, WN, TM, TN, OCC, 1, BM, ADM_CONV_KS2 ? 2 : 1>(k, prologue, m_tiles, s);
-      return launch_conv<WM, WN, TM, TN, OCC, 1, BM, 1>(k, prologue, m_tiles, s);
+      if (ADM_CONV_KS2 && k.C0 % 64 == 0 && k.C1 % 64 == 0) return launch_conv<WM, WN, TM, TN, OCC, 1, BM, ADM_CONV_KS2 ? 2 : 1, COLD>(k, prologue, m_tiles, s);
+      return launch_conv<WM, WN, TM, TN, OCC, 1, BM, 1, COLD>(k, prologue, m_tiles, s);
     }
   }
   ADM_FAIL(ADM_E_SHAPE, "adm_conv: %dx%d feature map does not tile into %d-pixel patches (need >= 8x8, power of two)",
@@ -1432,7 +1440,7 @@ int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
 // twice as many MFMAs as the retired 4-wave 128 / 96 / 64-wide tilings and beat them wherever those padded less).
 int pick_variant(const adm_conv_args* a) {
   if (a->variant != 0) return a->variant;
-  if (a->cout <= 16) return 3;
+  if (a->cout <= 16 || a->out_mode == 1) return 3;   // fp32 NCHW output is the heads' format (cout <= 16 in every model): the 16-wide tile carries it
   const int w192 = ((a->cout + 191) / 192) * 192, w128 = ((a->cout + 127) / 128) * 128;
   return w192 <= w128 ? 5 : 6;
 }
@@ -1610,12 +1618,12 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     ADM_REQUIRE(a->taps == 9 && !small_map && a->out_mode == 0 && k.ksplit <= 1 && !a->up_phase && a->prologue != 3, ADM_E_ARG,
                 "adm_conv: variant 8 takes 3x3 convs with bf16 output on maps >= 16x16");
     ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1 && k.TW == 16 && k.TH == 16, ADM_E_SHAPE, "adm_conv: variant 8 needs maps >= 16x16");
-    return launch_conv<2, 2, 8, 6, 1, 9, 324, 1>(k, a->prologue, k.N * k.tiles_x * k.tiles_y, s);
+    return launch_conv<2, 2, 8, 6, 1, 9, 324, 1, false>(k, a->prologue, k.N * k.tiles_x * k.tiles_y, s);
   }
   if (k.ksplit > 1) {
     int rc;
-    if (variant == 5) rc = small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, 9, a->prologue, s);
-    else rc = small_map ? dispatch_conv<2, 4, 4, 2, 2>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2>(k, 9, a->prologue, s);
+    if (variant == 5) rc = small_map ? dispatch_conv<2, 4, 4, 3, 2, true>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2, true>(k, 9, a->prologue, s);
+    else rc = small_map ? dispatch_conv<2, 4, 4, 2, 2, true>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2, true>(k, 9, a->prologue, s);
     if (rc != 0) return rc;
     const int hw = a->h * a->w;
     const int slabs = a->out_stats ? stat_slabs_for(a, variant) : (hw >= 1024 ? hw / 256 : 1);
@@ -1623,8 +1631,9 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
                        a->res, reinterpret_cast<uint16_t*>(a->out), a->out_stats, a->n, hw, a->cout, slabs);
     return adm_check_launch("adm_conv(split-K reduce)");
   }
+  ADM_REQUIRE(a->out_mode == 0 || variant == 3, ADM_E_ARG, "adm_conv: fp32 NCHW output runs on tiling variant 3 (the 16-wide tile)");
   switch (variant) {
-    case 3: return dispatch_conv<4, 1, 4, 1, 2>(k, a->taps, a->prologue, s);  // 256 x 16 (output head / stem backward)
+    case 3: return dispatch_conv<4, 1, 4, 1, 2, true>(k, a->taps, a->prologue, s);  // 256 x 16 (output head / stem backward)
     // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs
     case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, a->prologue, s);
     // 8 waves, 128-wide tile (channel counts that are multiples of 128 but not of 192: the classifier)

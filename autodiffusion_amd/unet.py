@@ -202,6 +202,7 @@ class AdmNet(HipModule):
                                           "(every reference launch script sets it True)")
 
     with_backward = False  # classifier: also pack the backward-data weight images
+    grad_scale = 1.0       # classifier with an fp16 backward network: static power-of-two scale of d(logits) (classifier.py)
 
     # ------------------------------------------------------------------ hipGraph replay
     # One UNet evaluation is ~700 launches, one guidance gradient ~1000: ~18 us of host time each through ctypes.  At the
@@ -332,7 +333,9 @@ class AdmNet(HipModule):
                 p = b.prefix
                 d = pr.blocks[p]
                 if isinstance(b, StemSpec):
-                    d["w_bwd"] = pack_bwd(P[f"{p}.weight"])
+                    # the LAST backward-data conv: 1 / grad_scale folded into its weights (exact: a power of two), see
+                    # EncoderUNetModel.grad_scale -- the fp16 backward network runs on d(logits) scaled up by it
+                    d["w_bwd"] = pack_bwd(P[f"{p}.weight"] * (1.0 / self.grad_scale))
                     zmax = max(zmax, b.cin, b.cout)
                 elif isinstance(b, ResBlockSpec):
                     d["w1_bwd"] = pack_bwd(P[f"{p}.in_layers.2.weight"])

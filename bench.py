@@ -312,7 +312,7 @@ def run_sd(args, rank, world, dev, red_dev, pin=None):
             ms = sum(p[0].elapsed_time(p[1]) for p in dom)
             fl = sum(p[2] for p in dom)
             tr, src = pmc_traffic("sd") if n == 6 else (None, None)
-            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)",
+            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1, false> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)",
                     "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": tr, "traffic_source": src, "launches": len(dom),
                     "avg_launch_us": round(ms * 1e3 / len(dom), 2), "avg_launch_gflop": round(fl / len(dom) / 1e9, 3)}
@@ -435,7 +435,7 @@ def run_candidate(args, rank, world, dev, red_dev, pin):
             ms = sum(p_[0].elapsed_time(p_[1]) for p_ in prof)
             fl = sum(p_[2] for p_ in prof)
             tr, src = pmc_traffic("guided")
-            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)",
+            roof = {"bound": "mfma", "kernel": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1, false> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)",
                     "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                     "traffic": None if tr is None else round(tr * bs / 256.0), "traffic_source":
@@ -503,6 +503,8 @@ def main():
     ap.add_argument("--torso", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type of the UNet torso: bf16 (BASELINE configs[1] names it) or fp16 (the reference's own "
                          "torso type, libadm_hip_f16.so: same kernels, 11 mantissa bits; the classifier's backward network stays bf16)")
+    ap.add_argument("--classifier-torso", default="bf16", choices=["bf16", "fp16"],
+                    help="the guidance classifier's element type, forward AND backward network (fp16: d(logits) runs scaled by 2^10)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the UNet evaluation and the guidance gradient as captured hipGraphs (small batches: the host's "
                          "~60 ms of launch work per guided step is the floor below batch ~100); the roofline's per-launch events "
@@ -567,8 +569,8 @@ def main():
     # the launch mix's dominant conv symbol: (tiling variant, taps, map > 8x8, prologue) -- 192-wide tiles for ADM-64's
     # multiples of 192 channels, 128-wide tiles for the 256-multiples of ADM-128 / LSUN-256
     dom_key = (6, 9, True, 2) if (w256 or w128) else (5, 9, True, 2)
-    dom_name = ("conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)" if (w256 or w128) else
-                "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)")
+    dom_name = ("conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1, false> (fused GN+SiLU+conv3x3, 256-pixel x 128-channel tile)" if (w256 or w128) else
+                "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1, false> (fused GN+SiLU+conv3x3, 256-pixel x 192-channel tile)")
     model, diffusion = create_model_and_diffusion(**args_to_dict(argparse.Namespace(**flags),
                                                                  model_and_diffusion_defaults().keys()))
     model.to(dev).randomize_(1234).convert_to_fp16()
@@ -580,6 +582,7 @@ def main():
             cf.update(image_size=size, classifier_depth=2 if w128 else 4)   # configs/128_guided_sample.sh:2 / search_imagenet64...sh:6
             classifier = create_classifier(**cf)
             classifier.to(dev).randomize_(4321)
+            classifier.set_torso(args.classifier_torso)
             if not hasattr(classifier, "log_prob_grad"):
                 raise NotImplementedError
         except (ImportError, NotImplementedError):
@@ -672,7 +675,7 @@ def main():
         eager_s = time.perf_counter() - t0e
     if ops.CONV_PROFILE is not None:
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        # dominant kernel symbol: conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1> = fused GN+SiLU prologue, 3x3 conv,
+        # dominant kernel symbol: conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1, false> = fused GN+SiLU prologue, 3x3 conv,
         # 256-pixel x 192-channel tile, 8 waves
         if args.conv_breakdown and rank == 0:
             agg = {}

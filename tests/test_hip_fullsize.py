@@ -149,6 +149,24 @@ def test_fp16_torso_matches_the_reference_at_its_own_precision():
         h = u8_hist(u8, gl[f"ddim_{tag}_uint8"])
         print(f"fp16 torso, full ADM-G-64 4-step DDIM loop ({'guided' if tag == 'g' else 'unguided'}): sample rel {rs:.3e}, uint8 within k levels {h}")
         assert rs < 6e-3 and h[2] >= 0.999, (tag, rs, h)
+    # the classifier in fp16 as well, FORWARD AND BACKWARD network (d(logits) scaled by 2^10, undone in the stem's backward weights:
+    # classifier.py EncoderUNetModel.grad_scale): the guidance gradient against the reference's fp32 autograd, 2.0e-2 in bf16
+    gc = golden("full_clf64")
+    c64h = clf(64, 4).set_torso("fp16")
+    assert c64h.compute_dtype == torch.float16 and c64h.grad_scale == 1024.0 and c64.grad_scale == 1.0
+    xc, tc, yc = (torch.from_numpy(gc[k]).to(DEV) for k in ("x", "t", "y"))
+    grad, logits = c64h.log_prob_grad(xc, tc, yc, 1.0, return_logits=True)
+    rl = float((logits.cpu() - torch.from_numpy(gc["logits"])).abs().max() / np.abs(gc["logits"]).max())
+    rg = rel(grad, gc["grad"])
+    print(f"fp16 classifier (forward + backward network, gradient scale 2^10): logits {rl:.3e}, guidance gradient rel {rg:.3e}")
+    assert torch.isfinite(grad).all() and rl < 2e-3 and rg < 8e-3, (rl, rg)
+    g3 = c64h.log_prob_grad(xc, tc, yc, 3.0)
+    assert rel(g3, (3.0 * grad).cpu()) < 8e-3
+    sample, u8 = guided_loop(model, diffusion, c64h, gl["cand"].tolist(), x_T, yl)
+    rs = rel(sample, gl["ddim_g_sample"])
+    h = u8_hist(u8, gl["ddim_g_uint8"])
+    print(f"fp16 UNet + fp16 classifier, guided loop: sample rel {rs:.3e}, uint8 within k levels {h}")
+    assert rs < 6e-3 and h[2] >= 0.999, (rs, h)
 
 
 def test_adm128_unet_classifier_and_guided_10_step_loop_match_the_reference():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r02_<tag>/pmc_<workload>_{FETCH,WRITE}_SIZE.csv (tools/profile_round.sh) -> profiles/r02/pmc_dominant_kernel_traffic.json
+"""gpurun_out/r03_<tag>/pmc_<workload>_{FETCH,WRITE}_SIZE.csv (tools/profile_round.sh) -> profiles/r03/pmc_dominant_kernel_traffic.json
 {workload: {kernel, launches, fetch_size_kb_per_launch, write_size_kb_per_launch, hbm_bytes_per_launch}} for the dominant
 kernel of each workload's bench line.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE tallies the
 128-byte requests of a 16 B/lane stream at 64 bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
@@ -9,8 +9,8 @@ import json
 import os
 import sys
 
-DOMINANT = {"guided": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1>", "unguided": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1>",
-            "adm256": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1>", "sd": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1>"}
+DOMINANT = {"guided": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1, false>", "unguided": "conv_kernel<2, 4, 8, 3, 2, 9, 324, 2, 1, false>",
+            "adm256": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1, false>", "adm128": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1, false>", "sd": "conv_kernel<2, 4, 8, 2, 2, 9, 324, 2, 1, false>"}
 
 
 def read(path, kernel, counter):

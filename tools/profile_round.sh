@@ -3,13 +3,13 @@
 #   bash tools/profile_round.sh <tag> [workloads...]        e.g.  bash tools/profile_round.sh v2 guided adm256 sd
 # Per workload W: (1) kernel stats of `bench.py --workload W` (kernel trace only), (2)+(3) HBM traffic counters in two
 # SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"),
-# reduced by tools/pmc_summary.py.  Writes gpurun_out/r02_<tag>/...; tools/pmc_traffic_json.py turns (2)+(3) into
-# profiles/r02/pmc_dominant_kernel_traffic.json.  The program after `--` is python3 itself (no env / bash hop).
+# reduced by tools/pmc_summary.py.  Writes gpurun_out/r03_<tag>/...; tools/pmc_traffic_json.py turns (2)+(3) into
+# profiles/r03/pmc_dominant_kernel_traffic.json.  The program after `--` is python3 itself (no env / bash hop).
 set -o pipefail
 TAG=${1:-v}
 shift
 WL=${@:-guided}
-OUT=gpurun_out/r02_$TAG
+OUT=gpurun_out/r03_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 for W in $WL; do
