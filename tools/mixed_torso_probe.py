@@ -74,7 +74,7 @@ def main():
         cases = [
             ("all bf16", lambda k, ds: False),
             ("all fp16", lambda k, ds: True),
-            ("fp16 at 64x64 only (level 0: 46 % of the FLOPs)", lambda k, ds: ds == 1),
+            ("fp16 at 64x64 only (25 % of the FLOPs)", lambda k, ds: ds == 1),
             ("fp16 at 64x64 + 32x32", lambda k, ds: ds <= 2),
             ("fp16 at 16x16 + 8x8 + middle", lambda k, ds: ds >= 4 and k != "head"),
             ("fp16 at 8x8 + middle only", lambda k, ds: ds >= 8 and k != "head"),
