@@ -137,7 +137,26 @@ class AttnPoolSpec:
         }
 
 
-Block = Union[StemSpec, ResBlockSpec, AttnSpec]
+@dataclass(frozen=True)
+class ResampleSpec:
+    """``Downsample`` / ``Upsample`` of a UNet built with ``resblock_updown=False`` (reference unet.py:78-141): a 3x3 stride-2 conv
+    (key ``<prefix>.op``) / nearest-neighbour 2x + 3x3 conv (key ``<prefix>.conv``) when ``use_conv`` (the constructor's
+    ``conv_resample``, True in every factory), else AvgPool2d(2) / plain nearest 2x.  Never a skippable layer (no layer_id:
+    dynamic_unet.py:556-561, 642-645 count only the ResBlock forms)."""
+    prefix: str
+    channels: int
+    down: bool
+    use_conv: bool = True
+    layer_id: int = -1
+
+    def param_shapes(self):
+        if not self.use_conv:
+            return {}
+        k = f"{self.prefix}.op" if self.down else f"{self.prefix}.conv"
+        return {f"{k}.weight": (self.channels, self.channels, 3, 3), f"{k}.bias": (self.channels,)}
+
+
+Block = Union[StemSpec, ResBlockSpec, AttnSpec, ResampleSpec]
 
 
 @dataclass
@@ -210,13 +229,13 @@ def build_unet_plan(
     dynamic: bool = False,
     encoder_only: bool = False,
     pool: str = "attention",
+    conv_resample: bool = True,
 ) -> UNetPlan:
     """Mirror of the reference constructors' bookkeeping (no tensors)."""
-    if not resblock_updown and len(channel_mult) > 1:
+    if not resblock_updown and len(channel_mult) > 1 and encoder_only:
         raise NotImplementedError(
-            "only resblock_updown=True is built (every reference launch script uses it); "
-            "conv Downsample/Upsample resampling is out of scope this round"
-        )
+            "classifier with classifier_resblock_updown=False: the backward-data network has no stride-2 conv "
+            "(every reference launch script and create_classifier's default use the ResBlock form)")
     if num_heads_upsample == -1:
         num_heads_upsample = num_heads
     emb_dim = model_channels * 4
@@ -247,10 +266,13 @@ def build_unet_plan(
             chans.append(ch)
             idx += 1
         if level != len(channel_mult) - 1:
-            plan.input_blocks.append([ResBlockSpec(f"input_blocks.{idx}.0", ch, ch, emb_dim,
-                                                   down=True, scale_shift=use_scale_shift_norm,
-                                                   layer_id=lid)])
-            lid += 1
+            if resblock_updown:
+                plan.input_blocks.append([ResBlockSpec(f"input_blocks.{idx}.0", ch, ch, emb_dim,
+                                                       down=True, scale_shift=use_scale_shift_norm,
+                                                       layer_id=lid)])
+                lid += 1
+            else:
+                plan.input_blocks.append([ResampleSpec(f"input_blocks.{idx}.0", ch, down=True, use_conv=conv_resample)])
             chans.append(ch)
             ds *= 2
             idx += 1
@@ -287,9 +309,12 @@ def build_unet_plan(
                 lid += 1
                 sub += 1
             if level and i == num_res_blocks:
-                seq.append(ResBlockSpec(f"output_blocks.{oidx}.{sub}", ch, ch, emb_dim, up=True,
-                                        scale_shift=use_scale_shift_norm, layer_id=lid))
-                lid += 1
+                if resblock_updown:
+                    seq.append(ResBlockSpec(f"output_blocks.{oidx}.{sub}", ch, ch, emb_dim, up=True,
+                                            scale_shift=use_scale_shift_norm, layer_id=lid))
+                    lid += 1
+                else:
+                    seq.append(ResampleSpec(f"output_blocks.{oidx}.{sub}", ch, down=False, use_conv=conv_resample))
                 ds //= 2
             plan.output_blocks.append(seq)
             oidx += 1

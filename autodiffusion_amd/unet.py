@@ -29,7 +29,7 @@ import torch
 
 from . import ops
 from ._lib import AdmError
-from .arch import AttnSpec, HeadSpec, ResBlockSpec, StemSpec, UNetPlan
+from .arch import AttnSpec, HeadSpec, ResBlockSpec, ResampleSpec, StemSpec, UNetPlan
 
 _ZERO_INIT_SUFFIXES = ("out_layers.3.weight", "out_layers.3.bias", "proj_out.weight", "proj_out.bias")
 
@@ -197,9 +197,9 @@ class AdmNet(HipModule):
         if plan.dynamic:
             self.layer_num = plan.layer_num
         for b in plan.all_blocks():
-            if isinstance(b, ResBlockSpec) and not b.scale_shift:
-                raise NotImplementedError("use_scale_shift_norm=False is not built on the HIP path "
-                                          "(every reference launch script sets it True)")
+            if isinstance(b, ResBlockSpec) and not b.scale_shift and self.with_backward:
+                raise NotImplementedError("classifier_use_scale_shift_norm=False: the backward-data network differentiates the FiLM form "
+                                          "only (create_classifier's default and every reference launch script use it)")
 
     with_backward = False  # classifier: also pack the backward-data weight images
     grad_scale = 1.0       # classifier with an fp16 backward network: static power-of-two scale of d(logits) (classifier.py)
@@ -305,7 +305,7 @@ class AdmNet(HipModule):
                 ws.append(f32(f"{p}.emb_layers.1.weight"))
                 bs.append(f32(f"{p}.emb_layers.1.bias"))
                 pr.film_off[p] = off
-                off += 2 * b.cout
+                off += (2 if b.scale_shift else 1) * b.cout   # (scale | shift), or the additive embedding of use_scale_shift_norm=False
                 d = dict(
                     g1=f32(f"{p}.in_layers.0.weight"), b1=f32(f"{p}.in_layers.0.bias"),
                     w1=pack(P[f"{p}.in_layers.2.weight"]), c1b=f32(f"{p}.in_layers.2.bias"),
@@ -318,6 +318,12 @@ class AdmNet(HipModule):
                 elif b.up:   # up-ResBlock: the first conv reads a 2x upsample -> four 2x2-tap phase convs (ops.pack_conv_weight_up)
                     d["w1_up"] = ops.pack_conv_weight_up(P[f"{p}.in_layers.2.weight"], cd)
                 pr.blocks[p] = d
+            elif isinstance(b, ResampleSpec):
+                if b.use_conv and b.down:     # 3x3 stride-2 conv at its own 9 taps per output pixel: the general conv2d kernel
+                    pr.blocks[p] = dict(w2d=ops.pack_conv2d_weight(P[f"{p}.op.weight"], None, cd), b=f32(f"{p}.op.bias"))
+                elif b.use_conv:              # conv3x3(nearest 2x): the virtual-upsample conv, as four 2x2-tap phase convs
+                    pr.blocks[p] = dict(w=pack(P[f"{p}.conv.weight"]), b=f32(f"{p}.conv.bias"),
+                                        w_up=ops.pack_conv_weight_up(P[f"{p}.conv.weight"], cd))
             elif isinstance(b, AttnSpec):
                 pr.blocks[p] = dict(
                     g=f32(f"{p}.norm.weight"), b=f32(f"{p}.norm.bias"),
@@ -394,6 +400,10 @@ class AdmNet(HipModule):
                                         want_stats=True)
             aff2 = (a2, b2)
             tape.append(("res", s, dict(x=x0, aff1=aff1, st1=st1, h1=h, aff2=aff2, st2=st2)))
+        elif not s.scale_shift:
+            # use_scale_shift_norm=False (reference unet.py:251-254): out_layers(h + emb_out).  h + e is never written: the statistics
+            # of x + e[n, c] follow from the conv epilogue's per-channel sums and e folds into the next conv's prologue affine
+            aff2 = ops.gn_affine(h, d["g2"], d["b2"], add=film[:, off:off + s.cout])
         else:
             aff2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total)
         if s.has_skip_conv:
@@ -401,6 +411,18 @@ class AdmNet(HipModule):
         else:
             res = xs
         return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, res_up=virtual_up, want_stats=True)
+
+    def _resample(self, pr, s: ResampleSpec, x):
+        """Downsample / Upsample of a resblock_updown=False model (reference unet.py:78-141)."""
+        if not s.use_conv:
+            return ops.resample(x, "down" if s.down else "up")
+        d = pr.blocks[s.prefix]
+        if s.down:
+            return ops.conv2d(x, d["w2d"], d["b"], 3, 3, stride=2, pad=(1, 1), relu=False)
+        if x.shape[1] >= 8 and x.shape[2] >= 8:
+            return ops.conv(x, d["w"], d["b"], s.channels, 9, in_up=True, want_stats=True,
+                            w_up=d["w_up"] if self.upconv_phases else None)
+        return ops.conv(ops.resample(x, "up"), d["w"], d["b"], s.channels, 9, want_stats=True)   # maps below 8x8: materialised
 
     def _attention(self, pr, s: AttnSpec, x, skipped, tape=None):
         if skipped:  # dynamic_unet.py:316-318
@@ -430,6 +452,8 @@ class AdmNet(HipModule):
                     tape.append(("stem", blk, {}))
             elif isinstance(blk, ResBlockSpec):
                 h = self._resblock(pr, blk, h, skip if first else None, film, blk.layer_id in skip_ids, tape)
+            elif isinstance(blk, ResampleSpec):
+                h = self._resample(pr, blk, h)
             else:
                 h = self._attention(pr, blk, h, blk.layer_id in skip_ids, tape)
             first = False

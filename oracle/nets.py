@@ -8,7 +8,7 @@ Restates:
   * ``timestep_embedding`` -- reference guided_diffusion/nn.py:103-121
   * ``GroupNorm32`` -- nn.py:17-19 (float32 statistics, 32 groups, eps 1e-5)
   * ``ResBlock._forward`` -- unet.py:236-256 (+ dynamic skip branch,
-    dynamic_unet.py:245-250)
+    dynamic_unet.py:245-250); ``Downsample`` / ``Upsample`` -- unet.py:78-141
   * ``AttentionBlock._forward`` -- unet.py:299-305 (+ dynamic_unet.py:316-318)
   * ``QKVAttention`` / ``QKVAttentionLegacy`` -- unet.py:361-393 / 328-358
   * ``UNetModel.forward`` -- unet.py:634-665;  ``Dynamic_UNetModel.forward``
@@ -23,7 +23,7 @@ from typing import Dict, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
-from autodiffusion_amd.arch import (AttnPoolSpec, AttnSpec, HeadSpec, ResBlockSpec, StemSpec,
+from autodiffusion_amd.arch import (AttnPoolSpec, AttnSpec, HeadSpec, ResBlockSpec, ResampleSpec, StemSpec,
                                     UNetPlan, GN_GROUPS)
 
 Params = Dict[str, torch.Tensor]
@@ -134,6 +134,14 @@ def _run_seq(P, seq, h, emb, skip_ids):
             h = resblock(P, blk, h, emb, skipped=blk.layer_id in skip_ids)
         elif isinstance(blk, AttnSpec):
             h = attention_block(P, blk, h, skipped=blk.layer_id in skip_ids)
+        elif isinstance(blk, ResampleSpec):   # Downsample / Upsample of resblock_updown=False models: reference unet.py:78-141
+            if blk.down:
+                h = (F.conv2d(h, P[f"{blk.prefix}.op.weight"], P[f"{blk.prefix}.op.bias"], stride=2, padding=1)
+                     if blk.use_conv else _down(h))
+            else:
+                h = _up(h)
+                if blk.use_conv:
+                    h = F.conv2d(h, P[f"{blk.prefix}.conv.weight"], P[f"{blk.prefix}.conv.bias"], padding=1)
         else:
             raise TypeError(blk)
     return h

@@ -92,8 +92,10 @@ def test_factory_signatures_defaults_and_state_dict_layout():
         create_classifier(**{**classifier_defaults(), "image_size": 32})
     clf = create_classifier(**{**classifier_defaults(), "classifier_width": 64, "classifier_depth": 1})
     assert clf.state_dict()["out.2.positional_embedding"].shape == (256, 65)
-    with pytest.raises(NotImplementedError):
-        create_model_and_diffusion(**{**d, "resblock_updown": False})
+    m2, _ = create_model_and_diffusion(**{**d, "resblock_updown": False})   # conv Downsample / Upsample: built since round 3 (tests/test_variants.py)
+    assert any(k.endswith(".op.weight") for k in m2.state_dict())
+    with pytest.raises(NotImplementedError):   # ... but not for the classifier, whose backward network has no stride-2 conv
+        create_classifier(**{**classifier_defaults(), "classifier_width": 64, "classifier_depth": 1, "classifier_resblock_updown": False})
 
 
 def test_hot_path_refuses_to_run_without_a_gpu():
