@@ -74,6 +74,22 @@ def main():
         cu = (xcc << 8) | (((hw_id >> 13) & 7) << 5) | (((hw_id >> 12) & 1) << 4) | ((hw_id >> 8) & 0xF)
         ncu = len(np.unique(cu))
         clk = ((buf[:, 9].astype(np.int64) - buf[:, 8].astype(np.int64)) / np.maximum(t[:, 2] - t[:, 1], 1)) * 100.0  # MHz
+        if os.environ.get("XCD_REPORT"):   # per-XCD balance of the static tile partition: when does each XCD's last tile end?
+            t0 = t[:, 0].min()
+            ends, busy, kclk = [], [], []
+            for xc in range(8):
+                m = xcc == xc
+                if not m.any():
+                    continue
+                ends.append((t[m, 6].max() - t0) / tick)
+                ncu_x = len(np.unique(cu[m]))
+                busy.append((t[m, 6] - t[m, 0]).sum() / tick / max(ncu_x, 1))
+                kclk.append(np.median(clk[m]))
+            per_cu_end = np.array([(t[cu == c, 6].max() - t0) / tick for c in np.unique(cu)])
+            print(f"    per XCD: last tile ends at {' '.join(f'{e:7.1f}' for e in ends)} us | busy per CU {' '.join(f'{b:7.1f}' for b in busy)} us | "
+                  f"k-loop clock {' '.join(f'{k:5.0f}' for k in kclk)} MHz")
+            print(f"    per CU: end of last tile min {per_cu_end.min():.1f} / median {np.median(per_cu_end):.1f} / max {per_cu_end.max():.1f} us "
+                  f"(spread {100 * (per_cu_end.max() - per_cu_end.min()) / per_cu_end.max():.1f} % of the kernel)")
         names = ["wait", "k-loop", "switch+stage", "park-next", "sweep", "stats"]
         sub = buf[:, [2, 10, 11, 12, 13, 3]].astype(np.int64)
         subd = np.diff(sub, axis=1) / tick
