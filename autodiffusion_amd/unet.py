@@ -248,8 +248,7 @@ class AdmNet(HipModule):
         dev = inputs[0].device
         # ... and the per-model launch-sequence switches: toggling one after the first replay must not keep the old capture
         key = key + tuple((tuple(t.shape), t.dtype) for t in inputs) + (torch.cuda.current_stream(dev).cuda_stream,
-                                                                       self.upconv_phases, getattr(self, "fuse_gn_bwd", None),
-                                                                       getattr(self, "fold_skip", None))
+                                                                       self.upconv_phases, getattr(self, "fuse_gn_bwd", None))
         entry = graphs.get(key)
         if entry is None:
             static_in = [t.clone() for t in inputs]

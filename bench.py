@@ -381,7 +381,7 @@ def run_candidate(args, rank, world, dev, red_dev, pin):
                                   batch_size=bs, num_samples=nimg, image_size=64, use_ddim=True, clip_denoised=True,
                                   class_cond=True, classifier_scale=1.0, seed=0, time_step=4, use_ddim_init_x=True,
                                   fid_on_device=True, use_graph=use_graph)
-    logger.log = lambda *a_, **k_: None   # the reference's per-batch "created N samples" lines go to log.txt in a search; not here
+    _log, logger.log = logger.log, (lambda *a_, **k_: None)   # the reference's per-batch "created N samples" lines belong to a search's log.txt
     searcher = EvolutionSearcher(sargs, model, diffusion, 4, classifier=classifier, features=features, feature_dim=dim,
                                  ref_stats=ref, population_parallel=True)
 
@@ -445,6 +445,7 @@ def run_candidate(args, rank, world, dev, red_dev, pin):
                     "how": f"one eager batch of {bs} after the timed region (the timed candidates replay hipGraphs, which carry no events), "
                            f"{eager_s * 1e3:.0f} ms with per-launch events"}
     chk = check_output(sample, u8)
+    logger.log = _log
     if rank == 0:
         ncand = world * args.steps
         per_cand = elapsed / args.steps
