@@ -67,6 +67,35 @@ class CandidateEvaluator:
         assert y is not None
         return self.classifier.log_prob_grad(x, t, y, self.classifier_scale)
 
+    def sample_batches(self, batch_size: int, seeds: Sequence[int]):
+        """len(seeds) reference batches of `batch_size` images in ONE pass over the networks -> [uint8 NHWC [B, H, W, 3]] per seed.
+
+        Bitwise the images of sample_batch(batch_size, seed) for every seed: each sub-batch draws its labels, x_T and per-step noise
+        from its own generator, and an image's result does not depend on how many images ride along (tests/test_hip_bigbatch.py).
+        The reference's search batch (100, a memory-driven flag) leaves the 16x16 / 8x8 levels with 200-300 tiles on 256 CUs; two
+        batches per pass fill the chip like the headline's 256."""
+        dev = self.device
+        gens = [torch.Generator(device=dev).manual_seed(int(s_) & 0x7FFFFFFFFFFFFFFF) for s_ in seeds]
+        shape1 = (batch_size, 3, self.image_size, self.image_size)
+        classes, noise = [], []
+        for g_ in gens:   # the draw order of sample_batch, per generator
+            classes.append(torch.randint(low=0, high=NUM_CLASSES, size=(batch_size,), device=dev, generator=g_))
+            noise.append(torch.randn(*shape1, device=dev, generator=g_))
+        classes, x_T = torch.cat(classes, 0), torch.cat(noise, 0)
+        d = self.active_diffusion
+        d.generator = [(g_, batch_size) for g_ in gens]
+        kwargs = {"y": classes}
+        if self.skip_layers is not None:
+            kwargs["skip_layers"] = self.skip_layers
+        fn = d.ddim_sample_loop if self.use_ddim else d.p_sample_loop
+        try:
+            fn(self._model_fn, tuple(x_T.shape), noise=x_T, clip_denoised=self.clip_denoised, model_kwargs=kwargs,
+               cond_fn=self._cond_fn if self.classifier is not None else None, device=dev)
+        finally:
+            d.generator = None
+        self.last_classes = classes
+        return list(d.last_uint8_nhwc.split(batch_size, 0))
+
     def sample_batch(self, batch_size: int, seed: Optional[int] = None, return_float: bool = False):
         """-> uint8 NHWC [B, H, W, 3] on the device (and the fp32 sample if return_float)."""
         dev = self.device

@@ -136,7 +136,12 @@ class SpacedDiffusion:
         if model_out.dtype != torch.float32:
             model_out = model_out.float()
         # drawn every step, as the reference does (keeps the RNG stream aligned with it)
-        if self.generator is not None:
+        if isinstance(self.generator, (list, tuple)):
+            # several reference batches evaluated in one pass (CandidateEvaluator.sample_batches): [(generator, images), ...] --
+            # every sub-batch draws from its own generator, so its images are those of its own separate evaluation
+            noise = torch.cat([torch.randn((cnt,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype, generator=g_)
+                               for g_, cnt in self.generator], 0)
+        elif self.generator is not None:
             noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=self.generator)
         else:
             noise = torch.randn_like(x)

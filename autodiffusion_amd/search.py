@@ -118,19 +118,26 @@ class EvolutionSearcher(object):
         host_images = []
         produced = 0
         batch_idx = 0
+        # rounds still to run (this rank takes one batch per round), and how many of them ride in one pass over the networks:
+        # images are bitwise those of separate passes (CandidateEvaluator.sample_batches), the chip is filled like the headline batch
+        rounds = -(-args.num_samples // (args.batch_size * world))
+        merge = int(getattr(args, "merge_batches", 0) or max(1, 256 // max(1, args.batch_size)))
         while produced < args.num_samples:
-            u8 = self._ev.sample_batch(args.batch_size, seed=seed0 + 7919 * (batch_idx * world + rank))
-            # the reference keeps arr[:num_samples] of the rank-major concatenation of every round
-            start = produced + rank * args.batch_size
-            keep = max(0, min(args.batch_size, args.num_samples - start))
-            if acc is not None:
-                if keep > 0:
-                    acc.add_from(self.features, u8[:keep])   # on a side stream, next to the next batch's sampling
-            else:
-                host_images.append(u8[:keep].cpu().numpy())
-            produced += args.batch_size * world
-            batch_idx += 1
-            logger.log('created ' + str(min(produced, batch_idx * args.batch_size * world)) + ' samples')
+            k = min(merge, rounds - batch_idx)
+            seeds = [seed0 + 7919 * ((batch_idx + j) * world + rank) for j in range(k)]
+            u8s = [self._ev.sample_batch(args.batch_size, seed=seeds[0])] if k == 1 else self._ev.sample_batches(args.batch_size, seeds)
+            for u8 in u8s:
+                # the reference keeps arr[:num_samples] of the rank-major concatenation of every round
+                start = produced + rank * args.batch_size
+                keep = max(0, min(args.batch_size, args.num_samples - start))
+                if acc is not None:
+                    if keep > 0:
+                        acc.add_from(self.features, u8[:keep])   # on a side stream, next to the next pass's sampling
+                else:
+                    host_images.append(u8[:keep].cpu().numpy())
+                produced += args.batch_size * world
+                batch_idx += 1
+                logger.log('created ' + str(min(produced, batch_idx * args.batch_size * world)) + ' samples')
         if world > 1:
             import torch.distributed as dist
             dist.barrier()

@@ -380,7 +380,7 @@ def run_candidate(args, rank, world, dev, red_dev, pin):
     sargs = types.SimpleNamespace(max_epochs=1, select_num=10, population_num=50, m_prob=0.25, crossover_num=15, mutation_num=25,
                                   batch_size=bs, num_samples=nimg, image_size=64, use_ddim=True, clip_denoised=True,
                                   class_cond=True, classifier_scale=1.0, seed=0, time_step=4, use_ddim_init_x=True,
-                                  fid_on_device=True, use_graph=use_graph)
+                                  fid_on_device=True, use_graph=use_graph, merge_batches=args.merge_batches)
     _log, logger.log = logger.log, (lambda *a_, **k_: None)   # the reference's per-batch "created N samples" lines belong to a search's log.txt
     searcher = EvolutionSearcher(sargs, model, diffusion, 4, classifier=classifier, features=features, feature_dim=dim,
                                  ref_stats=ref, population_parallel=True)
@@ -459,9 +459,10 @@ def run_candidate(args, rank, world, dev, red_dev, pin):
             "data": "synthetic (x_T ~ N(0,1), y ~ U{0..999}, random-init weights of the ADM-G-64, classifier and Inception-v3 architectures, "
                     "synthetic reference statistics): the FID VALUES mean nothing, the work is the real candidate's",
             "config": {"workload": f"get_cand_fid at the reference's search flags (search_imagenet64_classifier_guidance.sh: batch_size {bs}, "
-                                   f"num_samples {nimg}, 4-step candidates, classifier_scale 1.0), {args.torso}, "
+                                   f"num_samples {nimg}, 4-step candidates, classifier_scale 1.0), {args.merge_batches or max(1, 256 // bs)} batches per pass (bitwise the same images), {args.torso}, "
                                    f"{'hipGraph replay' if use_graph else 'eager launches'}, HIP Inception pool3 + f64 Gram + on-device Frechet distance",
                        "global_batch": world * bs, "image_size": 64, "sampler_steps": 4, "images_per_candidate": nimg,
+                       "batches_per_pass": args.merge_batches or max(1, 256 // bs),
                        "parallelism": f"dp{world} (population-parallel: one whole candidate per rank and step, no data-path collective)",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "images_per_sec": round(ncand * nimg / elapsed, 1),
@@ -501,6 +502,9 @@ def main():
                          "10 %% of the layers per step, seeded (the shape `--max_prun 0.1` candidates have)")
     ap.add_argument("--images", type=int, default=None, help="--workload candidate: images per candidate (default 5000)")
     ap.add_argument("--no-graph", action="store_true", help="--workload candidate: eager launches instead of hipGraph replay")
+    ap.add_argument("--merge-batches", type=int, default=0,
+                    help="--workload candidate: reference batches evaluated per pass over the networks (0 = auto: 256 // batch; 1 = one "
+                         "batch per pass as the reference does; the images are bitwise the same either way)")
     ap.add_argument("--torso", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type of the UNet torso: bf16 (BASELINE configs[1] names it) or fp16 (the reference's own "
                          "torso type, libadm_hip_f16.so: same kernels, 11 mantissa bits; the classifier's backward network stays bf16)")

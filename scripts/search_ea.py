@@ -12,7 +12,9 @@ not in this image).  With neither ``--features`` nor ``--inception_path`` the CL
 random-weight features is meaningless; ``--inception_random True`` opts in for throughput runs and tests, and every FID line
 of log.txt is then tagged "FID on RANDOM Inception weights".  ``--features pkg.module:factory``
 swaps in any callable ``factory(device) -> (features, dim)`` with ``features(uint8 NHWC device batch) -> fp32 [B, dim]``.
-``--ref_path`` is an .npz with ``mu``, ``sigma`` (written from the reference's pickled FIDStatistics).  ``--use_graph`` (default ``auto`` = on when ``--batch_size`` <= 128, e.g. the reference's 100) replays each UNet evaluation /
+``--ref_path`` is an .npz with ``mu``, ``sigma`` (written from the reference's pickled FIDStatistics).  ``--merge_batches`` (default 0 = auto: 256 // batch_size) evaluates that many reference batches per pass over the networks -- bitwise the
+same images (every sub-batch draws from its own generator, and an image's result does not depend on the batch it rides in), with the chip
+filled like the headline batch.  ``--use_graph`` (default ``auto`` = on when ``--batch_size`` <= 128, e.g. the reference's 100) replays each UNet evaluation /
 guidance gradient as a captured hipGraph: bit-identical, and at such batches the eager path is bound by the host's launch rate
 (one whole candidate at batch 100: 7.29 s instead of 7.61 s, bench.py --workload candidate).  ``--population_parallel True`` shards whole
 candidates over ranks; otherwise every candidate's images are sharded and the statistics pooled.
@@ -47,7 +49,7 @@ def create_argparser():
         time_step=100, seed=0, deterministic=False, local_rank=0, max_epochs=20, select_num=10, population_num=50,
         m_prob=0.1, crossover_num=25, mutation_num=35, classifier_path="", classifier_scale=1.0, max_fid=48.0,
         thres=0.2, use_ddim_init_x=False, search_space="", ref_path="", MASTER_PORT="12344", init_x="",
-        without_classifier=False, features="", inception_path="", inception_input="tf1", inception_random=False, population_parallel=False, fid_on_device=False, use_graph="auto",
+        without_classifier=False, features="", inception_path="", inception_input="tf1", inception_random=False, population_parallel=False, fid_on_device=False, use_graph="auto", merge_batches=0,
         index_step=None, max_prun=0.0, min_prun=0.0,
     )
     defaults.update(model_and_diffusion_defaults())

@@ -248,3 +248,35 @@ def test_get_cand_fid_with_a_reference_style_evaluator_object(monkeypatch):
                                      features=lambda u8: u8.reshape(u8.shape[0], -1).float() @ dev_proj)
     fid_dev = s_dev.get_cand_fid(cand=cand, args=args)
     assert np.isfinite(fid_host) and abs(fid_host - fid_dev) <= 1e-5 * max(1.0, abs(fid_dev)), (fid_host, fid_dev)
+
+
+def test_merged_reference_batches_are_bitwise_the_separate_ones(monkeypatch):
+    """CandidateEvaluator.sample_batches: several reference batches in one pass over the networks (get_cand_fid merges them up to the
+    headline batch) -- every sub-batch's uint8 images bitwise those of its own sample_batch call, for DDIM and DDPM (per-step noise from
+    the sub-batch's own generator), guided, with a layer-skip candidate; and the candidate's FID does not depend on the merge factor."""
+    from autodiffusion_amd import logger, search
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    from autodiffusion_amd.fid import FIDStatistics
+    model, clf, diffusion = _setup()
+    seeds = [11, 12, 13]
+    for use_ddim in (True, False):
+        ev = CandidateEvaluator(model, diffusion, clf, image_size=64, use_ddim=use_ddim, device=DEV)
+        for cand in ([153, 424, 926, 690], {"timesteps": [94, 217, 574], "skip_layers": [[1], [], [0, 5]]}):
+            ev.set_candidate(cand)
+            sep = [ev.sample_batch(3, seed=s_).clone() for s_ in seeds]
+            mer = ev.sample_batches(3, seeds)
+            assert len(mer) == 3 and all(torch.equal(a, b) for a, b in zip(mer, sep)), (use_ddim, cand)
+            assert ev.active_diffusion.generator is None
+    monkeypatch.setattr(logger, "log", lambda *a: None)
+    proj = torch.randn(3 * 64 * 64, 32, generator=torch.Generator().manual_seed(5)).to(DEV) / 100.0
+    features = lambda u8: u8.reshape(u8.shape[0], -1).float() @ proj  # noqa: E731
+    fids = []
+    for merge in (1, 2, 0):   # 0 = auto (256 // batch_size)
+        args = SimpleNamespace(max_epochs=1, select_num=2, population_num=3, m_prob=0.25, crossover_num=1, mutation_num=1,
+                               batch_size=4, num_samples=18, image_size=64, use_ddim=True, clip_denoised=True, class_cond=True,
+                               classifier_scale=1.0, seed=0, time_step=4, use_ddim_init_x=True, merge_batches=merge)
+        s = search.EvolutionSearcher(args, model, diffusion, 4, classifier=clf, features=features, feature_dim=32,
+                                     ref_stats=FIDStatistics(np.zeros(32), np.eye(32)))
+        fids.append(s.get_cand_fid(cand=[153, 424, 926, 690], args=args))
+        assert s.last_times["batches_this_rank"] == 5
+    assert fids[0] == fids[1] == fids[2], fids
