@@ -503,8 +503,9 @@ def main():
     ap.add_argument("--images", type=int, default=None, help="--workload candidate: images per candidate (default 5000)")
     ap.add_argument("--no-graph", action="store_true", help="--workload candidate: eager launches instead of hipGraph replay")
     ap.add_argument("--merge-batches", type=int, default=0,
-                    help="--workload candidate: reference batches evaluated per pass over the networks (0 = auto: 256 // batch; 1 = one "
-                         "batch per pass as the reference does; the images are bitwise the same either way)")
+                    help="reference batches evaluated per pass over the networks (images bitwise the same either way).  --workload candidate: "
+                         "0 = auto (256 // batch, what get_cand_fid does), 1 = one batch per pass as the reference does; image workloads "
+                         "(e.g. adm128, batch 32): default 1 = the reference's launch unit, K = what a search on this GPU runs at")
     ap.add_argument("--torso", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit element type of the UNet torso: bf16 (BASELINE configs[1] names it) or fp16 (the reference's own "
                          "torso type, libadm_hip_f16.so: same kernels, 11 mantissa bits; the classifier's backward network stays bf16)")
@@ -618,8 +619,16 @@ def main():
         fid_net.weights_loaded = True     # random weights on purpose (throughput run): no warning
         fid_acc = ActivationAccumulator(2048, dev)
 
+    MB = max(1, args.merge_batches)   # reference batches per pass over the networks (bitwise the same images: sample_batches)
+
     def one_step(step_idx, return_float=False):
         # deterministic, layout-independent seeding per (step, rank)
+        if MB > 1 and not return_float:
+            u8s = ev.sample_batches(B, [1000003 * step_idx + rank + 7919 * j for j in range(MB)])
+            if fid_net is not None:
+                for u8 in u8s:
+                    fid_acc.add_from(fid_net.features, u8)
+            return u8s[0]
         res = ev.sample_batch(B, seed=(1000003 * step_idx + rank), return_float=return_float)
         u8 = res[0] if return_float else res
         if fid_net is not None:
@@ -696,7 +705,7 @@ def main():
             fl = sum(p[2] for p in dom)
             achieved = fl / (ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(args.workload if args.workload != "auto" else "guided")
-            if traffic is not None and B != {"adm256": 64, "adm128": 32}.get(args.workload, 256):
+            if traffic is not None and B * MB != {"adm256": 64, "adm128": 32}.get(args.workload, 256):
                 traffic, traffic_src = None, None   # the committed figure is for the default batch
             roof = {"bound": "mfma", "kernel": dom_name,
                     "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -731,7 +740,7 @@ def main():
     chk = check_output(samplec, u8c)
 
     if rank == 0:
-        imgs = world * B * args.steps
+        imgs = world * B * MB * args.steps
         value = imgs / elapsed
         gflop_img = len(schedule) * (gflop_unet + (gflop_guide if guided else 0.0))
         if w256:
@@ -753,8 +762,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.torso == "bf16" else "f16",
             "data": ("synthetic (x_T ~ N(0,1), random-init weights of the ADM LSUN-256 architecture)" if w256 else
                      f"synthetic (x_T ~ N(0,1), y ~ U{{0..999}}, random-init weights of the ADM-G-{size} architecture)"),
-            "config": {"workload": wl,
-                       "global_batch": world * B, "image_size": size, "sampler_steps": len(schedule),
+            "config": {"workload": wl + (f"; {MB} such batches per pass over the networks (bitwise the same images), i.e. {MB * B} images per step and GPU" if MB > 1 else ""),
+                       "global_batch": world * B * MB, "batches_per_pass": MB, "image_size": size, "sampler_steps": len(schedule),
                        "parallelism": f"dp{world} (image-sharded, no data-path collective)",
                        "launch": "hipGraph replay" if args.graph else "eager",
                        "fid_stage_in_step": bool(args.with_fid)},
