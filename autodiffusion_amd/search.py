@@ -121,7 +121,8 @@ class EvolutionSearcher(object):
         # rounds still to run (this rank takes one batch per round), and how many of them ride in one pass over the networks:
         # images are bitwise those of separate passes (CandidateEvaluator.sample_batches), the chip is filled like the headline batch
         rounds = -(-args.num_samples // (args.batch_size * world))
-        merge = int(getattr(args, "merge_batches", 0) or max(1, 256 // max(1, args.batch_size)))
+        cap = 64 if int(getattr(args, "image_size", 64)) >= 256 else 256     # images per pass: the batches the bench lines are quoted at
+        merge = int(getattr(args, "merge_batches", 0) or max(1, cap // max(1, args.batch_size)))
         while produced < args.num_samples:
             k = min(merge, rounds - batch_idx)
             seeds = [seed0 + 7919 * ((batch_idx + j) * world + rank) for j in range(k)]

@@ -185,6 +185,12 @@ def test_sampling_cli_writes_the_reference_npz_format(tmp_path):
     assert z["arr_1"].shape == (6,) and z["arr_1"].dtype == np.int64
     log = open(os.path.join(str(tmp_path), "log.txt")).read()
     assert "sampling..." in log and "created 8 samples" in log and "sampling complete" in log
+    # the default evaluates both reference batches in one pass; --merge_batches 1 samples them one by one: the same file
+    os.makedirs(str(tmp_path / "one"), exist_ok=True)
+    out1 = mod.main(flags + ["--save_dir", str(tmp_path / "one"), "--use_timestep", "[153, 424, 926, 690]",
+                             "--skip_layers", "[[1],[],[0,5],[2,3]]", "--merge_batches", "1"])
+    z1 = np.load(out1)
+    assert np.array_equal(z1["arr_0"], z["arr_0"]) and np.array_equal(z1["arr_1"], z["arr_1"])
     import torch.distributed as dist
     if dist.is_initialized():
         dist.destroy_process_group()
