@@ -111,19 +111,80 @@ def check_output(sample, u8):
     return res
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpus(index):
+    """CPUs of the NUMA node GPU `index` hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist), or None if it cannot be read."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            return _cpulist(f.read()) or None
+    except Exception:
+        return None
+
+
+def cpu_core_key(cpu):
+    """The lowest-numbered hardware thread of the physical core `cpu` belongs to (its SMT siblings share the key)."""
+    try:
+        with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+            return min(_cpulist(f.read()))
+    except Exception:
+        return cpu
+
+
+def rank_cpu_slice(cpus, local_rank, local_world, local_of=None, ndev=1, core_key=None):
+    """The CPU slice of one local rank.  `cpus`: the CPUs the job may use; `local_of(device index)`: the CPUs local to that GPU's
+    NUMA node (None = unknown).  Ranks whose GPUs share a NUMA node split that node's CPUs among themselves (a launch thread
+    on the far socket pays the inter-socket hop on every doorbell write); without topology information the job's CPUs are cut
+    into `local_world` contiguous slices.  `core_key(cpu)` groups SMT siblings so that a slice holds whole physical cores.
+    Pure function (tests/test_bench_host.py)."""
+    if core_key is not None:   # keep the hardware threads of one physical core in one slice: two ranks never share a core
+        cpus = sorted(cpus, key=lambda c: (core_key(c), c))
+    if local_of is not None:
+        mine = local_of(local_rank % ndev)
+        if mine:
+            pool = [c for c in cpus if c in set(mine)]
+            peers = [r for r in range(local_world) if local_of(r % ndev) == mine]
+            if pool and local_rank in peers:
+                per = max(1, len(pool) // len(peers))
+                i = peers.index(local_rank)
+                got = pool[i * per:(i + 1) * per]
+                if got:
+                    return got
+    per = max(1, len(cpus) // local_world)
+    return cpus[local_rank * per:(local_rank + 1) * per] or cpus
+
+
 def pin_rank(local_rank, local_world):
     """One process per GPU on one node: every rank issues ~3400 launches per step from ONE Python thread; a rank whose
-    launch thread is descheduled stalls its GPU queue and the MAX-over-ranks time.  Each rank gets its own contiguous slice of
-    the CPUs this job may use (sched_setaffinity) and a thread budget of that size for OMP / torch intra-op pools
-    (ADM_BENCH_AFFINITY=0 leaves the process alone).  -> description for the JSON line."""
+    launch thread is descheduled stalls its GPU queue and the MAX-over-ranks time.  Each rank gets its own slice of the CPUs this
+    job may use -- of its GPU's NUMA node where the topology can be read (rank_cpu_slice) -- by sched_setaffinity, and a thread
+    budget of that size for OMP / torch intra-op pools (ADM_BENCH_AFFINITY=0 leaves the process alone).  -> description for the
+    JSON line."""
     if local_world <= 1 or os.environ.get("ADM_BENCH_AFFINITY", "1") == "0":
         return None
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return None
-    per = max(1, len(cpus) // local_world)
-    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    ndev = max(1, torch.cuda.device_count())
+    cache = {}
+
+    def local_of(i):
+        if i not in cache:
+            cache[i] = gpu_local_cpus(i) if torch.cuda.is_available() else None
+        return cache[i]
+    mine = sorted(rank_cpu_slice(cpus, local_rank, local_world, local_of, ndev, cpu_core_key))
+    numa = bool(local_of(local_rank % ndev))
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
@@ -131,7 +192,18 @@ def pin_rank(local_rank, local_world):
     nthr = max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", len(mine)))))
     os.environ["OMP_NUM_THREADS"] = str(nthr)
     torch.set_num_threads(nthr)
-    return {"cpus": f"{mine[0]}-{mine[-1]}", "n_cpus": len(mine), "threads": nthr}
+    def ranges(v):
+        out, a = [], None
+        for c in v + [None]:
+            if a is None:
+                a = b = c
+            elif c is not None and c == b + 1:
+                b = c
+            else:
+                out.append(f"{a}-{b}" if b != a else str(a))
+                a = b = c
+        return ",".join(out)
+    return {"cpus": ranges(mine), "n_cpus": len(mine), "threads": nthr, "numa_local": numa}
 
 
 def gather_ranks(world, rank, local_rank, dev, elapsed_local, pin, backend):

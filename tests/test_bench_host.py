@@ -60,3 +60,28 @@ def test_pmc_traffic_names_its_source():
     if v is not None:
         assert v > 0 and "committed constant" in src and "profiles/r0" in src
     assert bench.pmc_traffic("no-such-workload") == (None, None)
+
+
+def test_rank_cpu_slice_follows_the_gpu_numa_node():
+    """8 ranks on a two-socket node (CPUs 0-63 + 128-191 on socket 0, 64-127 + 192-255 on socket 1; GPUs 0-3 on socket 0, 4-7 on
+    socket 1): every rank gets CPUs of its own GPU's socket, disjoint from the other ranks'; without topology: contiguous slices."""
+    cpus = list(range(256))
+    s0 = list(range(0, 64)) + list(range(128, 192))
+    s1 = list(range(64, 128)) + list(range(192, 256))
+    local_of = lambda i: s0 if i < 4 else s1   # noqa: E731
+    got = [bench.rank_cpu_slice(cpus, r, 8, local_of, 8) for r in range(8)]
+    assert all(len(g) == 32 for g in got) and len(set(c for g in got for c in g)) == 256
+    assert all(set(got[r]) <= set(s0 if r < 4 else s1) for r in range(8))
+    flat = [bench.rank_cpu_slice(cpus, r, 8, None, 8) for r in range(8)]
+    assert flat[3] == list(range(96, 128)) and len(set(c for g in flat for c in g)) == 256
+    # two ranks rehearsing on ONE GPU share its node's CPUs, disjointly
+    two = [bench.rank_cpu_slice(cpus, r, 2, lambda i: s0, 1) for r in range(2)]
+    assert not set(two[0]) & set(two[1]) and set(two[0]) | set(two[1]) == set(s0)
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # SMT siblings (cpu c and c + 128) stay together: no two ranks share a physical core
+    key = lambda c: c % 128   # noqa: E731
+    smt = [bench.rank_cpu_slice(cpus, r, 8, local_of, 8, key) for r in range(8)]
+    cores = [set(key(c) for c in g) for g in smt]
+    assert all(len(g) == 32 and len(k) == 16 for g, k in zip(smt, cores))
+    assert all(not (cores[i] & cores[j]) for i in range(8) for j in range(i))
+    assert all(set(smt[r]) <= set(s0 if r < 4 else s1) for r in range(8))
