@@ -90,3 +90,17 @@ def test_bench_candidate_workload_line():
     assert abs(out["images_per_sec"] - 24 / ts["per_candidate"]) <= 0.02 * out["images_per_sec"] + 0.1
     assert len(out["fid_values"]) == 2 and all(f == f for f in out["fid_values"])
     assert out["output_check"]["finite"] is True and out["roofline"]["launches"] > 0
+
+
+def test_bench_merged_batches_line():
+    """--merge-batches K on an image workload: K reference batches per pass (bitwise the same images), value counts all of them."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "unguided", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--merge-batches", "3", "--no-cpu-baseline", "--no-kernel-events"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["batches_per_pass"] == 3 and out["config"]["global_batch"] == 12
+    assert abs(out["value"] - 12 / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]
+    assert out["output_check"]["finite"] is True and out["output_check"]["u8_shape"] == [4, 64, 64, 3]
