@@ -68,7 +68,7 @@ struct ConvK {
   int ntiles16, nblocks_n;
   int total_tiles;           // pixel tiles x Cout blocks (x K splits) (persistent launch: blocks walk this list)
   unsigned wbytes;
-  // split-K (3x3, small batches: a launch with few tiles but a long K loop): the tile list is multiplied by `ksplit`,
+  // split-K (small batches: a launch with few tiles but a long K loop; 3x3, and 1x1 of the wide low-resolution levels): the tile list is multiplied by `ksplit`,
   // split s runs chunks [s * cps, (s + 1) * cps) (cps even: the halo double buffer keeps its parity) from zero
   // accumulators and stores them as fp32 [ksplit][N*H*W][Cout] into `ws`; conv_splitk_reduce adds the splits in a fixed
   // order together with bias and residual, rounds to bf16 and accumulates the output statistics
@@ -456,22 +456,24 @@ conv_kernel(const ConvK p) {
   uint4 wr[WRING][TN];
   uint4 ring[ADM_CONV_RD][PASSES];
   float4 bs[TN];
-  const int last = chunks - 1;
+  // 1x1 loops: `last` = the tile's last chunk, ce - 1 (chunks - 1 unless the K loop is split: the split 1x1 tile runs chunks
+  // [cb, ce) with cb even, so buffer parities (c & 1) and the first chunk in halo[0] agree)
   auto first_loads = [&](int lq_) {
+    const int last = ce - 1;
     if constexpr (T3) {
       load_w(cb * 9, wr[0]);
       load_w(cb * 9 + 1, wr[1]);
     } else {
       if constexpr (KS == 1) {
-        load_w(0, wr[0]);
-        load_w(min(1, last), wr[1]);
-        load_w(min(2, last), wr[2]);
+        load_w(cb, wr[0]);
+        load_w(min(cb + 1, last), wr[1]);
+        load_w(min(cb + 2, last), wr[2]);
       } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) load_w(ks, wr[ks]);  // stage 0's K-steps
       }
 #pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(1, last), ps);
+      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(cb + 1, last), ps);
 #if ADM_CONV_RD == 3
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) ring[2][ps] = halo_load(min(2, last), ps);
@@ -668,6 +670,7 @@ conv_kernel(const ConvK p) {
       // the activation loads the raw loop is 48 % shorter; weights and the barrier are not the limit.)
       using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+      const int last = ce - 1;
 #if ADM_CONV_RD == 3
       if constexpr (KS == 1) {
         // experiment: three activation stages in flight, weights two K-steps ahead (rings of 3, unrolled by 3)
@@ -707,7 +710,7 @@ conv_kernel(const ConvK p) {
         // (Peeling the tail so that the unrolled group has no early exit removes the s_waitcnt vmcnt(0) hipcc puts
         // at the loop header, but the 192-wide GN-prologue instantiation then spills inside the loop: 530 -> 690 us
         // on qkv 384->1152 @32^2; the 128-wide tile, which does not spill, gained 3 %.)
-        for (int c0 = 0; c0 < chunks; c0 += 4) {
+        for (int c0 = cb; c0 < ce; c0 += 4) {   // cb: 0, or even (split-K)
           body(c0, I0{}, I0{});
           body(c0 + 1, I1{}, I1{});
           body(c0 + 2, I0{}, I2{});
@@ -1421,7 +1424,7 @@ int dispatch_conv(ConvK& k, int taps, int prologue, hipStream_t s) {
         return launch_conv<WM, WN, TM, TN, OCC, 9, 200, 1, COLD>(k, prologue, m_tiles, s);
       }
     }
-  } else if constexpr (!COLD || WN == 1) {   // 1x1: never split-K; fp32 NCHW output only on the 16-wide tile
+  } else {   // 1x1 (COLD: split-K on the 8-wave tiles, fp32 NCHW output on the 16-wide tile)
     if (conv_geometry(k, BM, 1, BM)) {
       const int m_tiles = k.TI == 1 ? k.N * k.tiles_x * k.tiles_y : (k.N + k.TI - 1) / k.TI;
       // 64-channel stages (two K-steps per barrier) when neither source straddles a stage
@@ -1570,8 +1573,8 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   k.ws = a->ws;
   if (k.ksplit > 1) {
     const int chunks = (a->c0 + a->c1) / KC;
-    ADM_REQUIRE(a->taps == 9 && a->out_mode == 0 && !k.res_up && a->ws, ADM_E_ARG,
-                "adm_conv: ksplit needs a 3x3 conv with bf16 output, no res_up and a workspace");
+    ADM_REQUIRE(a->out_mode == 0 && !k.res_up && a->ws, ADM_E_ARG, "adm_conv: ksplit needs bf16 output, no res_up and a workspace");
+    ADM_REQUIRE(a->taps == 9 || (ADM_CONV_KS2 == 0 && ADM_CONV_RD == 2), ADM_E_ARG, "adm_conv: this build's 1x1 loop does not split K");
     ADM_REQUIRE(chunks % k.ksplit == 0 && (chunks / k.ksplit) % 2 == 0, ADM_E_SHAPE,
                 "adm_conv: ksplit %d does not divide the %d 32-channel chunks into even runs", k.ksplit, chunks);
     ADM_REQUIRE(a->cout % 8 == 0 && a->cout <= 2048 && adm_aligned16(a->ws), ADM_E_SHAPE, "adm_conv: ksplit needs cout %% 8 == 0, cout <= 2048, aligned ws");
@@ -1622,8 +1625,8 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   }
   if (k.ksplit > 1) {
     int rc;
-    if (variant == 5) rc = small_map ? dispatch_conv<2, 4, 4, 3, 2, true>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2, true>(k, 9, a->prologue, s);
-    else rc = small_map ? dispatch_conv<2, 4, 4, 2, 2, true>(k, 9, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2, true>(k, 9, a->prologue, s);
+    if (variant == 5) rc = small_map ? dispatch_conv<2, 4, 4, 3, 2, true>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2, true>(k, a->taps, a->prologue, s);
+    else rc = small_map ? dispatch_conv<2, 4, 4, 2, 2, true>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2, true>(k, a->taps, a->prologue, s);
     if (rc != 0) return rc;
     const int hw = a->h * a->w;
     const int slabs = a->out_stats ? stat_slabs_for(a, variant) : (hw >= 1024 ? hw / 256 : 1);

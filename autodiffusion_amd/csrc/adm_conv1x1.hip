@@ -423,7 +423,7 @@ int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
 int adm_conv1x1_resident_cfg(const adm_conv_args* a, int* wm_out) {
   static const bool disabled = getenv("ADM_CONV_NO_RESIDENT") != nullptr;  // A/B switch for measurements
   if (disabled && a->variant == 0) return 0;
-  if (a->taps != 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 10)) return 0;
+  if (a->taps != 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 10) || a->ksplit > 1) return 0;   // split-K: the staged kernel
   const int k = a->c0 + a->c1, hw = a->h * a->w;
   if (k % 64 != 0 || a->c0 % 8 != 0 || a->c1 % 8 != 0 || a->cout % 8 != 0 || hw % 64 != 0) return 0;
   // narrow outputs: the 2 x 4 wave layout measured no faster than the staged kernel (its K loop is weight-load bound

@@ -282,6 +282,22 @@ def splitk_for(h: int, w: int, cin: int) -> int:
     return max(1, want)
 
 
+SPLITK_1X1_MIN_CHUNKS = int(os.environ.get("ADM_SPLITK_1X1_MIN_CHUNKS", "32"))
+
+
+def splitk_1x1_for(h: int, w: int, cin: int, cout: int) -> int:
+    """Split-K factor of a 1x1 conv by SHAPE only (as splitk_for): the wide projections of the 16x16 / 8x8 levels of a small-batch
+    model (SD v1: 1280 -> 1280 attention / feed-forward outputs, 5120 -> 1280 after the GEGLU) have 30-60 output tiles with
+    40-160-chunk K loops on 256 CUs.  Runs of an even number of >= 8 chunks; outputs wider than 1280 have tiles enough."""
+    chunks = cin // 32
+    if h * w > 256 or chunks < SPLITK_1X1_MIN_CHUNKS or cout > 1280:
+        return 1
+    want = 8
+    while want > 1 and (chunks % want or (chunks // want) % 2 or chunks // want < 8):
+        want //= 2
+    return max(1, want)
+
+
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
          out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1,
          w_up=None, gnb=None, geglu=False):
@@ -337,8 +353,8 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.in_up, a.res_up = int(in_up), int(res_up)
     ws = None
     if ksplit > 1:
-        if taps != 9 or out_f32_nchw or res_up:
-            raise AdmError("conv(ksplit > 1): 3x3 convs with bf16 output only")
+        if out_f32_nchw or res_up:
+            raise AdmError("conv(ksplit > 1): 16-bit NHWC output only, no res_up")
         ws = torch.empty((ksplit, n * h * w, cout), dtype=torch.float32, device=dev)
         a.ksplit, a.ws = int(ksplit), ws.data_ptr()
     if in_up or res_up:

@@ -38,6 +38,10 @@ _HEAD_WIDTHS = (32, 48, 64, 80, 96, 128, 160, 192, 256)
 # Downsample (openaimodel.py:149-152): the stride-2 3x3 conv at its own 9 taps per OUTPUT pixel (adm_conv2d), or as a stride-1
 # conv on the faster tile kernel + an every-second-pixel pick (4 x the MACs); A/B switch ADM_SD_STRIDE2
 STRIDE2_TAPS = os.environ.get("ADM_SD_STRIDE2", "1") != "0"
+# with enable_splitk(): also the wide 1x1 projections of the 16x16 / 8x8 levels.  OFF by default -- measured (same box, SD v1 bench, two runs
+# each): off 63.4 / 63.8, every 1280-wide projection split 61.8 / 61.7, only the 5120 -> 1280 ones 63.3 / 63.1 latents/s: the two guidance
+# half batches on two streams already fill the CUs a 30-60-tile launch leaves idle, and the split adds fp32 partials + a reduce launch
+SPLITK_1X1 = os.environ.get("ADM_SD_SPLITK_1X1", "0") != "0"
 
 
 def _padded_head(d: int) -> int:
@@ -196,27 +200,27 @@ class UNetModel(HipModule):
         scale = float(s.d_head) ** -0.5
         zb = pr.zero_bias
         aff = ops.gn_affine(x, d["g"], d["b"], eps=1e-6)
-        h = ops.conv(x, d["w_in"], d["b_in"], inner, 1, aff=aff, silu=False)
+        h = ops.conv(x, d["w_in"], d["b_in"], inner, 1, aff=aff, silu=False, ksplit=self._ks1(x, c, inner))
         for li, L in enumerate(d["layers"]):
             # self-attention
             y = ops.layernorm(h, *L["norm1"])
             qkv = ops.conv(y, L["qkv1"], zb, 3 * hd, 1).view(n, t, 3 * hd)
             a = ops.attention_cross(qkv, qkv[:, :, hd:], heads, dp, t, scale)
-            h = ops.conv(a.view(n, hh, ww, hd), L["o1"], L["o1b"], inner, 1, res=h)
+            h = ops.conv(a.view(n, hh, ww, hd), L["o1"], L["o1b"], inner, 1, res=h, ksplit=self._ks1(x, hd, inner))
             # cross-attention over the conditioning tokens
             y = ops.layernorm(h, *L["norm2"])
-            q = ops.conv(y, L["q2"], zb, hd, 1).view(n, t, hd)
+            q = ops.conv(y, L["q2"], zb, hd, 1, ksplit=self._ks1(x, inner, hd)).view(n, t, hd)
             kv = kvs[(s.prefix, li)]
             a = ops.attention_cross(q, kv.view(n, -1, 2 * hd), heads, dp, n_ctx, scale)
-            h = ops.conv(a.view(n, hh, ww, hd), L["o2"], L["o2b"], inner, 1, res=h)
+            h = ops.conv(a.view(n, hh, ww, hd), L["o2"], L["o2b"], inner, 1, res=h, ksplit=self._ks1(x, hd, inner))
             # gated feed-forward
             y = ops.layernorm(h, *L["norm3"])
             if self.fuse_geglu and "ff1g" in L and t % 64 == 0:
                 gl = ops.conv(y, L["ff1g"], L["ff1gb"], 8 * inner, 1, geglu=True)    # [n, hh, ww, 4 * inner]: u never exists
             else:
                 gl = ops.geglu(ops.conv(y, L["ff1"], L["ff1b"], 8 * inner, 1))
-            h = ops.conv(gl, L["ff2"], L["ff2b"], inner, 1, res=h)
-        return ops.conv(h, d["w_out"], d["b_out"], c, 1, res=x, want_stats=True)
+            h = ops.conv(gl, L["ff2"], L["ff2b"], inner, 1, res=h, ksplit=self._ks1(x, 4 * inner, inner))
+        return ops.conv(h, d["w_out"], d["b_out"], c, 1, res=x, want_stats=True, ksplit=self._ks1(x, inner, c))
 
     def _run_seq(self, pr, seq, h, skip, emb, kvs, n_ctx, x_nchw=None):
         first = True
@@ -267,6 +271,9 @@ class UNetModel(HipModule):
 
     def _ks(self, t, cin):
         return ops.splitk_for(t.shape[1], t.shape[2], cin) if self.small_batch_splitk else 1
+
+    def _ks1(self, t, cin, cout):   # the transformer's wide 1x1 projections at 16x16 / 8x8 (ops.splitk_1x1_for)
+        return ops.splitk_1x1_for(t.shape[1], t.shape[2], cin, cout) if self.small_batch_splitk and SPLITK_1X1 else 1
 
     def enable_graph(self, flag: bool = True):
         """Capture the ~700 launches of one evaluation in a hipGraph per (latent shape, context shape) and replay it:

@@ -163,7 +163,7 @@ typedef struct adm_conv_args {
                         prologue is applied on the way): ResBlock(up=True)'s h_upd(in_layers[:-1](x)) without the
                         upsampled tensor ever existing.  3x3, bf16 output, c1 == 0, variant 0/5/6 only */
   int32_t res_up;    /* 1: res is [n][h/2][w/2][cout], added through the same virtual upsample (x_upd(x)) */
-  int32_t ksplit;    /* > 1: split-K for small batches (3x3, bf16 output, variant 5 / 6): the K loop of every output tile is
+  int32_t ksplit;    /* > 1: split-K for small batches (3x3 or 1x1, bf16 output, variant 5 / 6): the K loop of every output tile is
                         cut into `ksplit` runs of (c0 + c1) / 32 / ksplit chunks (an even count) that run as separate
                         tiles into `ws`, and a reduce pass adds them in index order with bias, residual and the output
                         statistics.  Deterministic; the result depends on ksplit (fp32 summation order), not on n */

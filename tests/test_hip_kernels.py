@@ -414,9 +414,27 @@ def test_conv_fused_output_statistics_feed_groupnorm(ops, n, hw, cin, cout, taps
 def test_conv_split_k_matches_the_one_pass_conv(ops, n, hw, c0, c1, cout, ks, pro, use_res):
     """adm_conv with ksplit > 1 (K loop of every tile cut into runs that go out as separate tiles, fp32 partial sums,
     deterministic reduce with bias / residual / output statistics) against fp32 torch and against the one-pass kernel."""
+    _split_k_case(ops, 9, n, hw, c0, c1, cout, ks, pro, use_res)
+
+
+@pytest.mark.parametrize("n,hw,c0,c1,cout,ks,pro,use_res", [
+    (6, 16, 1280, 0, 1280, 4, 0, True),     # SD v1: attention / feed-forward output projections at 16x16 (runs of 10 chunks)
+    (3, 8, 1024, 0, 320, 8, 0, True),       # 8x8 level, 128-pixel tiles (two images per tile), ragged last tile and Cout block; runs of 4 chunks
+    (2, 16, 512, 0, 192, 4, 1, False),      # GroupNorm prologue (the transformer's proj_in); the staged kernel serves cout < 256 without the split too
+    (2, 16, 256, 256, 384, 2, 2, True),     # virtual concat, split at the source boundary, GN + SiLU prologue
+    (1, 32, 128, 0, 256, 2, 0, False),      # a 32x32 map (4 tiles per image), runs of 2 chunks
+])
+def test_conv1x1_split_k_matches_the_one_pass_conv(ops, n, hw, c0, c1, cout, ks, pro, use_res):
+    """The same for 1x1 convs (the staged kernel's 1x1 loop over chunks [cb, ce); without the split most of these shapes run on
+    the resident-tile kernel): SD v1's 1280-wide projections at 6-latent half batches are 30-60 tiles of 40-160 chunks."""
+    _split_k_case(ops, 1, n, hw, c0, c1, cout, ks, pro, use_res)
+
+
+def _split_k_case(ops, taps, n, hw, c0, c1, cout, ks, pro, use_res):
     cin = c0 + c1
+    kk = 3 if taps == 9 else 1
     x = bf(rnd((n, cin, hw, hw), 1))
-    w = bf(rnd((cout, cin, 3, 3), 2, (cin * 9) ** -0.5))
+    w = bf(rnd((cout, cin, kk, kk), 2, (cin * taps) ** -0.5))
     b = 0.1 * rnd((cout,), 3)
     res = bf(rnd((n, cout, hw, hw), 4)) if use_res else None
     a = 1 + 0.1 * rnd((n, cin), 5)
@@ -427,7 +445,7 @@ def test_conv_split_k_matches_the_one_pass_conv(ops, n, hw, c0, c1, cout, ks, pr
         if pro == 2:
             xin = F.silu(xin)
         xin = bf(xin)
-    ref = F.conv2d(xin, w, b, padding=1)
+    ref = F.conv2d(xin, w, b, padding=kk // 2)
     if use_res:
         ref = bf(ref) + res
     xd = nhwc_dev(x)
@@ -435,16 +453,16 @@ def test_conv_split_k_matches_the_one_pass_conv(ops, n, hw, c0, c1, cout, ks, pr
     wp = ops.pack_conv_weight(w.to(DEV))
     kw = dict(x1=x1, aff=(a.to(DEV), sh.to(DEV)) if pro else None, silu=(pro == 2), res=nhwc_dev(res) if use_res else None,
               want_stats=True)
-    y1 = ops.conv(x0, wp, b.to(DEV), cout, 9, **kw)
-    yk = ops.conv(x0, wp, b.to(DEV), cout, 9, ksplit=ks, **kw)
+    y1 = ops.conv(x0, wp, b.to(DEV), cout, taps, **kw)
+    yk = ops.conv(x0, wp, b.to(DEV), cout, taps, ksplit=ks, **kw)
     assert_close_bf16(nchw_cpu(yk), ref, f"split-K x{ks}")
     d = (nchw_cpu(yk) - nchw_cpu(y1)).abs().max().item()
     assert d <= 2e-2 * ref.abs().max().item(), d          # same values up to the last bf16 digit (fp32 order differs)
-    assert torch.equal(ops.conv(x0, wp, b.to(DEV), cout, 9, ksplit=ks, **kw), yk)   # deterministic
+    assert torch.equal(ops.conv(x0, wp, b.to(DEV), cout, taps, ksplit=ks, **kw), yk)   # deterministic
     if n > 1:   # the result does not depend on the batch the image rides in
         kw1 = dict(kw, x1=None if x1 is None else x1[:1].contiguous(), aff=None if not pro else (a[:1].to(DEV), sh[:1].to(DEV)),
                    res=None if not use_res else nhwc_dev(res[:1]))
-        assert torch.equal(ops.conv(x0[:1].contiguous(), wp, b.to(DEV), cout, 9, ksplit=ks, **kw1), yk[:1])
+        assert torch.equal(ops.conv(x0[:1].contiguous(), wp, b.to(DEV), cout, taps, ksplit=ks, **kw1), yk[:1])
     # the reduce pass's output statistics feed GroupNorm like the one-pass epilogue's
     gamma, beta = (1 + 0.2 * rnd((cout,), 7)).to(DEV), (0.1 * rnd((cout,), 8)).to(DEV)
     a1, b1 = ops.gn_affine(yk, gamma, beta)

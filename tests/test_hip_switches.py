@@ -93,11 +93,12 @@ def test_fid_accumulation_without_the_side_stream(monkeypatch):
 
 def test_sd_unet_non_default_schedules(monkeypatch):
     """ADM_SD_FUSE_GEGLU=0 (projection -> tensor -> adm_geglu), ADM_SD_STRIDE2=0 (Downsample as stride-1 conv + pixel pick),
-    ADM_SD_SPLITK (split-K on / off), ADM_UPCONV_PHASES=0 on the reference-captured w320 fixture; ADM_SD_SPLIT_GUIDANCE=0 (one batch of
+    ADM_SD_SPLITK (split-K on / off; ADM_SD_SPLITK_1X1=1: the wide 1x1 projections too), ADM_UPCONV_PHASES=0 on the reference-captured w320 fixture; ADM_SD_SPLIT_GUIDANCE=0 (one batch of
     2N instead of two half batches on two streams) bitwise equal through the DDIM sampler."""
     from autodiffusion_amd import sd_unet
     from test_hip_sd import _model, check
     from test_sd_oracle import sd_case
+    from autodiffusion_amd.ops import splitk_1x1_for as ops_splitk_1x1
     g, plan, P = sd_case("sd_unet_w320")
     x, t, ctx = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "context"))
     m = _model(plan, P)
@@ -113,6 +114,13 @@ def test_sd_unet_non_default_schedules(monkeypatch):
     check(m(x, t, ctx), g["out"], "sd w320, Downsample as stride-1 conv + pick")
     monkeypatch.setattr(sd_unet, "STRIDE2_TAPS", True)
     check(m.enable_splitk(True)(x, t, ctx), g["out"], "sd w320, split-K")
+    monkeypatch.setattr(sd_unet, "SPLITK_1X1", True)      # ADM_SD_SPLITK_1X1=1: the 1280-wide 1x1 projections of the 16x16 / 8x8 levels too
+    from autodiffusion_amd import ops as _ops
+    monkeypatch.setattr(_ops, "SPLITK_1X1_MIN_CHUNKS", 8)  # the fixture's widest level has 640 channels (SD v1: 1280): lower the threshold so that its
+    widths = {b.inner for seq in plan.input_blocks + [plan.middle_block] + plan.output_blocks for b in seq if hasattr(b, "inner")}   # projections split
+    assert any(ops_splitk_1x1(8, 8, k, c) > 1 for c in widths for k in (c, 4 * c)), widths
+    check(m(x, t, ctx), g["out"], "sd w320, split-K incl. the wide 1x1 projections")
+    monkeypatch.setattr(sd_unet, "SPLITK_1X1", False)
     m.enable_splitk(False)
     check(m.enable_upconv_phases(False)(x, t, ctx), g["out"], "sd w320, one-launch Upsample convs")
     m.enable_upconv_phases(True)
