@@ -27,6 +27,21 @@ SHAPES = [
     ("clf bwd 128->128 @64 raw", 256, 64, 128, 0, 128, 9, 0, False),
 ]
 
+# SHAPESET=wide: the 512- / 1024-channel levels of ADM-G-128 (256 x (1,1,2,3,4)) and LSUN-256 (256 x (1,1,2,2,4,4)): which tile width
+# (VARIANT=5: 192, pads 512 -> 576 and 1024 -> 1152; VARIANT=6: 128, no padding) serves them better?
+WIDE = [
+    ("adm 512->512 @64 3x3 gn+res", 32, 64, 512, 0, 512, 9, 2, True),
+    ("adm 512->512 @32 3x3 gn+res", 64, 32, 512, 0, 512, 9, 2, True),
+    ("adm 768|512->512 @32 3x3 cat", 64, 32, 768, 512, 512, 9, 2, False),
+    ("adm 1024->1024 @16 3x3 gn+res", 64, 16, 1024, 0, 1024, 9, 2, True),
+    ("adm 1024->1024 @8 3x3 gn+res", 64, 8, 1024, 0, 1024, 9, 2, True),
+    ("adm 256->256 @128 3x3 gn+res", 32, 128, 256, 0, 256, 9, 2, True),
+    ("clf 512->512 @8 3x3", 256, 8, 512, 0, 512, 9, 2, True),
+    ("clf bwd 512->512 @8 raw", 256, 8, 512, 0, 512, 9, 0, False),
+]
+if os.environ.get("SHAPESET") == "wide":
+    SHAPES = WIDE
+
 
 def main():
     reps = int(os.environ.get("REPS", "5"))
