@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")
 # the same kernels built with IEEE half as the 16-bit element type (csrc/adm_common.h, -DADM_ACT_F16): the reference's own
 # torso precision (use_fp16=True); selected per tensor dtype by ops.py, per model by `torso="fp16"` / ADM_TORSO=fp16
 LIB_PATH_F16 = os.environ.get("ADM_HIP_LIB_F16") or os.path.join(_HERE, "libadm_hip_f16.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class AdmError(RuntimeError):
@@ -85,7 +85,7 @@ SIGNATURES = {
     "adm_attention_lse": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_attention_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_gn_bwd_partial": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "adm_gn_bwd_finalize": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "adm_gn_bwd_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "adm_gn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "adm_grad_add": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "adm_logsoftmax_grad": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
@@ -97,7 +97,7 @@ SIGNATURES = {
     "adm_attention_cross": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "adm_layernorm": (_I, [_P, _P, _P, _P, C.c_int64, _I, _F, _P]),
     "adm_geglu": (_I, [_P, _P, C.c_int64, _I, _P]),
-    "adm_gn_finalize_add": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "adm_gn_finalize_add": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "adm_sd_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(SdStepCoefs), _P]),
     "adm_dpm_step": (_I, [_P, _P, _P, _P, _P, _P, C.c_int64, _F, _F, _F, _F, _F, _F, _P]),
     "adm_fid_accumulate": (_I, [_P, _P, _P, _I, _I, _P]),
@@ -106,6 +106,11 @@ SIGNATURES = {
     "adm_pool2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "adm_global_avgpool_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "adm_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "adm_channel_mean": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "adm_bcast_add": (_I, [_P, _I, _F, _P, _P, _I, _I, _I, _P]),
+    "adm_vec_act": (_I, [_P, _P, _P, C.c_int64, _I, _P]),
+    "adm_vec_gn": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "adm_vec_gn_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
 }
 
 _libs = {}

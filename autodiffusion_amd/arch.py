@@ -138,6 +138,28 @@ class AttnPoolSpec:
 
 
 @dataclass(frozen=True)
+class PoolHeadSpec:
+    """The classifier's other heads (reference unet.py:826-856): pool = "adaptive" (GN -> SiLU -> AdaptiveAvgPool2d(1) -> conv1x1 ->
+    Flatten), "spatial" (Linear(F, 2048) -> ReLU -> Linear over the concatenated per-block channel means, F = ``_feature_size``:
+    the stem's, every input block's and the middle block's channels) or "spatial_v2" (Linear -> GroupNorm32(32, 2048) -> SiLU -> Linear)."""
+    prefix: str          # "out"
+    kind: str
+    channels: int        # of the final feature map
+    feature_size: int    # F (spatial pools)
+    out_dim: int
+    hidden: int = 2048
+
+    def param_shapes(self):
+        p, c, o, f, hd = self.prefix, self.channels, self.out_dim, self.feature_size, self.hidden
+        if self.kind == "adaptive":
+            return {f"{p}.0.weight": (c,), f"{p}.0.bias": (c,), f"{p}.3.weight": (o, c, 1, 1), f"{p}.3.bias": (o,)}
+        if self.kind == "spatial":
+            return {f"{p}.0.weight": (hd, f), f"{p}.0.bias": (hd,), f"{p}.2.weight": (o, hd), f"{p}.2.bias": (o,)}
+        return {f"{p}.0.weight": (hd, f), f"{p}.0.bias": (hd,), f"{p}.1.weight": (hd,), f"{p}.1.bias": (hd,),
+                f"{p}.3.weight": (o, hd), f"{p}.3.bias": (o,)}
+
+
+@dataclass(frozen=True)
 class ResampleSpec:
     """``Downsample`` / ``Upsample`` of a UNet built with ``resblock_updown=False`` (reference unet.py:78-141): a 3x3 stride-2 conv
     (key ``<prefix>.op``) / nearest-neighbour 2x + 3x3 conv (key ``<prefix>.conv``) when ``use_conv`` (the constructor's
@@ -232,10 +254,8 @@ def build_unet_plan(
     conv_resample: bool = True,
 ) -> UNetPlan:
     """Mirror of the reference constructors' bookkeeping (no tensors)."""
-    if not resblock_updown and len(channel_mult) > 1 and encoder_only:
-        raise NotImplementedError(
-            "classifier with classifier_resblock_updown=False: the backward-data network has no stride-2 conv "
-            "(every reference launch script and create_classifier's default use the ResBlock form)")
+    if not resblock_updown and not conv_resample and len(channel_mult) > 1 and encoder_only:
+        raise NotImplementedError("classifier with AvgPool2d down-sampling (conv_resample=False): create_classifier never builds it")
     if num_heads_upsample == -1:
         num_heads_upsample = num_heads
     emb_dim = model_channels * 4
@@ -284,12 +304,14 @@ def build_unet_plan(
     ]
     lid += 3
     if encoder_only:
-        if pool != "attention":
-            raise NotImplementedError(f"classifier pool={pool!r}: only 'attention' is built "
-                                      "(the reference default, script_util.py:38)")
-        if num_head_channels == -1:
-            raise AssertionError("attention pool needs num_head_channels")
-        plan.head = AttnPoolSpec("out", ch, image_size // ds, num_head_channels, out_channels)
+        if pool == "attention":
+            if num_head_channels == -1:
+                raise AssertionError("attention pool needs num_head_channels")
+            plan.head = AttnPoolSpec("out", ch, image_size // ds, num_head_channels, out_channels)
+        elif pool in ("adaptive", "spatial", "spatial_v2"):
+            plan.head = PoolHeadSpec("out", pool, ch, sum(chans) + ch, out_channels)   # chans: the stem + every input block; + the middle block
+        else:
+            raise NotImplementedError(f"Unexpected {pool} pooling")
         plan.layer_num = lid
         return plan
     oidx = 0

@@ -19,7 +19,7 @@ import torch
 
 from . import ops
 from ._lib import AdmError
-from .arch import AttnPoolSpec, UNetPlan
+from .arch import AttnPoolSpec, PoolHeadSpec, UNetPlan
 from .unet import AdmNet
 
 
@@ -28,8 +28,8 @@ class EncoderUNetModel(AdmNet):
     fuse_gn_bwd = ops.FUSE_GN_BWD   # a per-model choice (never by batch): the fused sums are taken per 256-pixel tile
 
     def __init__(self, plan: UNetPlan, use_fp16: bool = False):
-        if not plan.encoder_only or not isinstance(plan.head, AttnPoolSpec):
-            raise ValueError("EncoderUNetModel needs an encoder plan with the attention pool head")
+        if not plan.encoder_only or not isinstance(plan.head, (AttnPoolSpec, PoolHeadSpec)):
+            raise ValueError("EncoderUNetModel needs an encoder plan with a pool head")
         super().__init__(plan, use_fp16)
 
     # The backward-data network's tensors are tiny: d(logits) <= 1, and 40 layers later the medians sit at 4e-6 .. 5e-4, with up to
@@ -46,8 +46,20 @@ class EncoderUNetModel(AdmNet):
 
     # ------------------------------------------------------------------ head weights
     def _prepare_head(self, pr, P, f32):
-        h: AttnPoolSpec = self.plan.head
+        h = self.plan.head
         p = h.prefix
+        if isinstance(h, PoolHeadSpec):
+            t = lambda k: f32(k).t().contiguous()   # noqa: E731  (backward-data: the transposed Linear)
+            if h.kind == "adaptive":
+                wc = f32(f"{p}.3.weight").reshape(h.out_dim, h.channels).contiguous()
+                pr.head = dict(g=f32(f"{p}.0.weight"), b=f32(f"{p}.0.bias"), wc=wc, bc=f32(f"{p}.3.bias"), wc_t=wc.t().contiguous())
+            else:
+                last = "2" if h.kind == "spatial" else "3"
+                pr.head = dict(w0=f32(f"{p}.0.weight"), b0=f32(f"{p}.0.bias"), w0_t=t(f"{p}.0.weight"),
+                               wc=f32(f"{p}.{last}.weight"), bc=f32(f"{p}.{last}.bias"), wc_t=t(f"{p}.{last}.weight"))
+                if h.kind == "spatial_v2":
+                    pr.head.update(g1=f32(f"{p}.1.weight"), b1=f32(f"{p}.1.bias"))
+            return
         wc = f32(f"{p}.2.c_proj.weight").reshape(h.out_dim, h.channels).contiguous()
         pr.head = dict(
             g=f32(f"{p}.0.weight"), b=f32(f"{p}.0.bias"), pos=f32(f"{p}.2.positional_embedding"),
@@ -60,14 +72,52 @@ class EncoderUNetModel(AdmNet):
 
     # ------------------------------------------------------------------ forward
     def _features(self, pr, x, timesteps, tape):
+        """-> (final map, feat): feat = the concatenated per-block channel means of the spatial pools (unet.py:884-893), else None."""
         film = self._embed(pr, timesteps, None)
+        hs = self.plan.head
+        spatial = isinstance(hs, PoolHeadSpec) and hs.kind.startswith("spatial")
+        feat = torch.empty((x.shape[0], hs.feature_size), dtype=torch.float32, device=x.device) if spatial else None
+        col = 0
+
+        def keep(h):
+            nonlocal col
+            if spatial:
+                ops.channel_mean(h, out=feat, col=col)
+                if tape is not None:
+                    tape.append(("feat", None, dict(col=col, shape=tuple(h.shape), dtype=h.dtype)))
+                col += h.shape[3]
         h = None
         for seq in self.plan.input_blocks:
             h = self._run_seq(pr, seq, h, None, film, (), x_nchw=x, tape=tape)
-        return self._run_seq(pr, self.plan.middle_block, h, None, film, (), tape=tape)
+            keep(h)
+        h = self._run_seq(pr, self.plan.middle_block, h, None, film, (), tape=tape)
+        keep(h)
+        assert not spatial or col == hs.feature_size
+        return h, feat
 
-    def _head_forward(self, pr, h, tape):
-        hs: AttnPoolSpec = self.plan.head
+    def _pool_head_forward(self, pr, hs: PoolHeadSpec, h, feat, tape):
+        hd = pr.head
+        if hs.kind == "adaptive":     # GN -> SiLU -> AdaptiveAvgPool2d((1, 1)) -> conv1x1 -> Flatten
+            if tape is not None:
+                a_, b_, st = ops.gn_affine(h, hd["g"], hd["b"], want_stats=True)
+                tape.append(("adaptive", hs, dict(h=h, aff=(a_, b_), st=st)))
+            else:
+                a_, b_ = ops.gn_affine(h, hd["g"], hd["b"])
+            return ops.linear_f32(ops.channel_mean(h, (a_, b_)), hd["wc"], hd["bc"])
+        z1 = ops.linear_f32(feat, hd["w0"], hd["b0"])
+        if hs.kind == "spatial":      # Linear -> ReLU -> Linear
+            if tape is not None:
+                tape.append(("spatial", hs, dict(z1=z1)))
+            return ops.linear_f32(ops.vec_act(z1, "relu"), hd["wc"], hd["bc"])
+        y, st = ops.vec_gn(z1, hd["g1"], hd["b1"])    # Linear -> GroupNorm32(32, 2048) -> SiLU -> Linear
+        if tape is not None:
+            tape.append(("spatial_v2", hs, dict(z1=z1, y=y, st=st)))
+        return ops.linear_f32(y, hd["wc"], hd["bc"], silu_in=True)
+
+    def _head_forward(self, pr, h, tape, feat=None):
+        hs = self.plan.head
+        if isinstance(hs, PoolHeadSpec):
+            return self._pool_head_forward(pr, hs, h, feat, tape)
         hd = pr.head
         n, hh, ww, c = h.shape
         if hh * ww != 64:
@@ -103,7 +153,8 @@ class EncoderUNetModel(AdmNet):
             return _ClassifierFn.apply(x, timesteps, self)
         with torch.no_grad():
             x = x.to(torch.float32).contiguous()
-            return self._head_forward(pr, self._features(pr, x, timesteps, None), None)
+            h, feat = self._features(pr, x, timesteps, None)
+            return self._head_forward(pr, h, None, feat)
 
     # ------------------------------------------------------------------ backward-data
     def _bwd_conv(self, pr, dy, w_bwd, cout, taps):
@@ -115,16 +166,34 @@ class EncoderUNetModel(AdmNet):
         with torch.no_grad():
             x = x.detach().to(torch.float32).contiguous()
             tape = []
-            logits = self._head_forward(pr, self._features(pr, x, timesteps, tape), tape)
+            h, feat = self._features(pr, x, timesteps, tape)
+            logits = self._head_forward(pr, h, tape, feat)
         return logits, tape
 
     def _backward_tape(self, tape, dl):
         """dl = d(loss)/d(logits) fp32 [N, 1000] -> d(loss)/dx fp32 [N,3,H,W] (data gradients only)."""
         pr = self._packed
         with torch.no_grad():
-            g = None
+            g = dfeat = None
             for kind, s, t in reversed(tape):
-                if kind == "pool":
+                if kind == "adaptive":
+                    hd = pr.head
+                    n, hh, ww, c = t["h"].shape
+                    dact = ops.bcast_add(ops.linear_f32(dl, hd["wc_t"], None), t["h"].shape, t["h"].dtype, 1.0 / (hh * ww))
+                    g = ops.gn_bwd(t["h"], dact, t["aff"], t["st"], silu=True)
+                elif kind == "spatial":
+                    hd = pr.head
+                    dfeat = ops.linear_f32(ops.vec_act(t["z1"], "relu", dy=ops.linear_f32(dl, hd["wc_t"], None)), hd["w0_t"], None)
+                elif kind == "spatial_v2":
+                    hd = pr.head
+                    dy = ops.vec_act(t["y"], "silu", dy=ops.linear_f32(dl, hd["wc_t"], None))
+                    dfeat = ops.linear_f32(ops.vec_gn_bwd(t["z1"], hd["g1"], t["st"], dy), hd["w0_t"], None)
+                elif kind == "feat":     # this block's channel means fed the spatial head: d mean / d h = 1 / HW on every pixel
+                    shp = t["shape"]
+                    g = ops.bcast_add(dfeat, shp, t["dtype"], 1.0 / (shp[1] * shp[2]), add=g, col=t["col"])
+                elif kind == "down":     # Downsample's 3x3 stride-2 conv: stride-1 backward conv over the zero-inserted gradient
+                    g = self._bwd_conv(pr, ops.resample(g, "zero2"), pr.blocks[s.prefix]["w_bwd"], s.channels, 9)
+                elif kind == "pool":
                     hd = pr.head
                     n, hh, ww, c = t["h"].shape
                     da0 = ops.linear_f32(dl, hd["wc_t"], None)
@@ -147,10 +216,10 @@ class EncoderUNetModel(AdmNet):
                     fuse2 = self.fuse_gn_bwd and _gnb_ok(t["h1"])
                     if fuse2:
                         dz2 = ops.conv(g, d["w2_bwd"], pr.zero_bias, s.cout, 9, gnb=(t["h1"], t["aff2"]))
-                        dh1 = ops.gn_bwd(t["h1"], dz2, t["aff2"], t["st2"], silu=True, partial=dz2._adm_stats[0])
+                        dh1 = ops.gn_bwd(t["h1"], dz2, t["aff2"], t["st2"], silu=True, partial=dz2._adm_stats[0], norm_add=t["add2"])
                     else:
                         d_act2 = self._bwd_conv(pr, g, d["w2_bwd"], s.cout, 9)
-                        dh1 = ops.gn_bwd(t["h1"], d_act2, t["aff2"], t["st2"], silu=True)
+                        dh1 = ops.gn_bwd(t["h1"], d_act2, t["aff2"], t["st2"], silu=True, norm_add=t["add2"])
                     if s.down:
                         d_in = self._bwd_conv(pr, dh1, d["w1_bwd"], s.cin, 9)
                         g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, dy_half=True, add=g, add_half=True)

@@ -88,7 +88,8 @@ gn_bwd_partial_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
 // 2.9 % of the guided step (profiles/r02/bench_guided_b256_b_kernel_stats.csv).
 __global__ void __launch_bounds__(256)
 gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ aa, const float* __restrict__ stats,
-                       float* __restrict__ k1, float* __restrict__ k0, int c, int hw, int slabs) {
+                       const float* __restrict__ add, int add_stride, float* __restrict__ k1, float* __restrict__ k0, int c, int hw,
+                       int slabs) {
   const int img = blockIdx.x;
   const int cpg = c / 32;
   const int grp = blockIdx.y * 8 + threadIdx.x / 32, sub = threadIdx.x % 32;
@@ -97,9 +98,13 @@ gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restric
   const float* ab = aa + (long long)img * c + grp * cpg;
   const int items = slabs * cpg;     // item i = (slab i / cpg, channel-in-group i % cpg)
   double s1 = 0.0, s2 = 0.0;
+  // add: the layer normalised x + e[img, ch] (use_scale_shift_norm = False) while x is what was stored and summed:
+  // sum dz (x + e) = sum dz x + e sum dz, and dx = a dz + k1 (x + e) + k0 keeps its form with k0 += k1 e
+  const float* eb = add ? add + (long long)img * add_stride + grp * cpg : nullptr;
   auto at = [&](int i, float2& v, float& a) {
     const int sl = i / cpg, j = i - sl * cpg;
     v = *reinterpret_cast<const float2*>(pb + ((long long)sl * c + j) * 2);
+    if (eb) v.y += eb[j] * v.x;
     a = ab[j];
   };
   auto acc = [&](const float2& v, float a) {
@@ -130,7 +135,7 @@ gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restric
   const float f1 = (float)kk1, f0 = (float)(-(double)rstd * s1 / m - (double)mean * kk1);
   for (int j = sub; j < cpg; j += 32) {
     k1[(long long)img * c + grp * cpg + j] = f1;
-    k0[(long long)img * c + grp * cpg + j] = f0;
+    k0[(long long)img * c + grp * cpg + j] = eb ? f0 + f1 * eb[j] : f0;
   }
 }
 
@@ -422,12 +427,13 @@ extern "C" int adm_gn_bwd_partial(const adm_bf16* x, const adm_bf16* dy, const f
   return adm_check_launch("adm_gn_bwd_partial");
 }
 
-extern "C" int adm_gn_bwd_finalize(const float* partial, const float* aff_a, const float* stats, float* k1, float* k0,
-                                   int n, int c, int hw, int slabs, void* stream) {
+extern "C" int adm_gn_bwd_finalize(const float* partial, const float* aff_a, const float* stats, const float* add, int add_stride,
+                                   float* k1, float* k0, int n, int c, int hw, int slabs, void* stream) {
   ADM_REQUIRE(partial && aff_a && stats && k1 && k0, ADM_E_ARG, "adm_gn_bwd_finalize: null pointer");
   ADM_REQUIRE(n > 0 && c % 32 == 0 && hw > 0 && slabs > 0, ADM_E_SHAPE, "adm_gn_bwd_finalize: bad shape");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, partial, aff_a, stats, k1, k0,
-                     c, hw, slabs);
+  ADM_REQUIRE(!add || add_stride >= c, ADM_E_ARG, "adm_gn_bwd_finalize: add_stride < c");
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, partial, aff_a, stats, add, add_stride,
+                     k1, k0, c, hw, slabs);
   return adm_check_launch("adm_gn_bwd_finalize");
 }
 

@@ -204,11 +204,12 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
 }
 
 // ------------------------------------------------------------------------------------ resample
-template <int MODE, bool ACT>  // MODE 1: avgpool2, 2: nearest x2, 3: every second pixel (stride-2 subsample)
+template <int MODE, bool ACT>  // MODE 1: avgpool2, 2: nearest x2, 3: every second pixel (stride-2 subsample), 4: zero-insert x2 (out[2y][2x] = in[y][x], 0 elsewhere:
+                                // the input of a stride-2 conv's backward-data conv)
 __global__ void __launch_bounds__(256)
 resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a, const float* __restrict__ aff_b,
                 uint16_t* __restrict__ out, int n, int h, int w, int c) {
-  const int oh = MODE == 2 ? h * 2 : h / 2, ow = MODE == 2 ? w * 2 : w / 2;
+  const int oh = (MODE == 2 || MODE == 4) ? h * 2 : h / 2, ow = (MODE == 2 || MODE == 4) ? w * 2 : w / 2;
   const int cg = c / 8;
   const long long items = (long long)n * oh * ow * cg;
   for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
@@ -216,6 +217,10 @@ resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a
     const int g = (int)(it % cg);
     const long long opix = it / cg;
     const int ox = (int)(opix % ow), oy = (int)((opix / ow) % oh), img = (int)(opix / ((long long)ow * oh));
+    if (MODE == 4 && ((oy | ox) & 1)) {
+      *reinterpret_cast<uint4*>(out + opix * c + g * 8) = make_uint4(0u, 0u, 0u, 0u);
+      continue;
+    }
     float a8[8], b8[8];
     if (ACT) {
       *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(aff_a + (long long)img * c + g * 8);
@@ -227,8 +232,8 @@ resample_kernel(const uint16_t* __restrict__ in, const float* __restrict__ aff_a
     constexpr int TAPS = MODE == 1 ? 4 : 1;
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
-      const int iy = MODE == 1 ? oy * 2 + tp / 2 : (MODE == 2 ? oy / 2 : oy * 2);
-      const int ix = MODE == 1 ? ox * 2 + tp % 2 : (MODE == 2 ? ox / 2 : ox * 2);
+      const int iy = MODE == 1 ? oy * 2 + tp / 2 : ((MODE == 2 || MODE == 4) ? oy / 2 : oy * 2);
+      const int ix = MODE == 1 ? ox * 2 + tp % 2 : ((MODE == 2 || MODE == 4) ? ox / 2 : ox * 2);
       const uint4 v = *reinterpret_cast<const uint4*>(in + (((long long)img * h + iy) * w + ix) * c + g * 8);
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -320,12 +325,12 @@ extern "C" int adm_gn_finalize(const float* partial, const float* gamma, const f
 }
 
 extern "C" int adm_gn_finalize_add(const float* partial, const float* gamma, const float* beta, const float* add,
-                                   int add_stride, float* aff_a, float* aff_b, int n, int c, int hw, int slabs, float eps,
+                                   int add_stride, float* aff_a, float* aff_b, float* stats, int n, int c, int hw, int slabs, float eps,
                                    void* stream) {
   ADM_REQUIRE(partial && gamma && beta && add && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize_add: null pointer");
   ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0 && add_stride >= c, ADM_E_SHAPE, "adm_gn_finalize_add: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
-                     (const float*)nullptr, 0, 0, gamma, beta, (const float*)nullptr, 0, aff_a, aff_b, (float*)nullptr, hw, eps,
+                     (const float*)nullptr, 0, 0, gamma, beta, (const float*)nullptr, 0, aff_a, aff_b, stats, hw, eps,
                      add, add_stride);
   return adm_check_launch("adm_gn_finalize_add");
 }
@@ -348,12 +353,13 @@ extern "C" int adm_resample(const adm_bf16* in, const float* aff_a, const float*
                             int w, int c, int mode, void* stream) {
   ADM_REQUIRE(in && out, ADM_E_ARG, "adm_resample: null pointer");
   ADM_REQUIRE((aff_a != nullptr) == (aff_b != nullptr), ADM_E_ARG, "adm_resample: aff_a/aff_b go together");
-  ADM_REQUIRE(mode >= 1 && mode <= 3, ADM_E_ARG, "adm_resample: mode must be 1 (avgpool2), 2 (nearest x2) or 3 (stride-2 subsample)");
+  ADM_REQUIRE(mode >= 1 && mode <= 4, ADM_E_ARG, "adm_resample: mode must be 1 (avgpool2), 2 (nearest x2), 3 (stride-2 subsample) or 4 (zero-insert x2)");
+  ADM_REQUIRE(mode != 4 || !aff_a, ADM_E_ARG, "adm_resample: zero-insert takes no affine");
   ADM_REQUIRE(n > 0 && h > 0 && w > 0 && c % 8 == 0, ADM_E_SHAPE, "adm_resample: bad shape");
-  ADM_REQUIRE(mode == 2 || (h % 2 == 0 && w % 2 == 0), ADM_E_SHAPE, "adm_resample: odd size for a 2x reduction");
+  ADM_REQUIRE(mode == 2 || mode == 4 || (h % 2 == 0 && w % 2 == 0), ADM_E_SHAPE, "adm_resample: odd size for a 2x reduction");
   ADM_REQUIRE(adm_aligned16(in) && adm_aligned16(out) && adm_aligned16(aff_a) && adm_aligned16(aff_b), ADM_E_ALIGN,
               "adm_resample: unaligned pointer");
-  const int oh = mode == 2 ? h * 2 : h / 2, ow = mode == 2 ? w * 2 : w / 2;
+  const int oh = (mode == 2 || mode == 4) ? h * 2 : h / 2, ow = (mode == 2 || mode == 4) ? w * 2 : w / 2;
   const long long items = (long long)n * oh * ow * (c / 8);
   int blocks = (int)((items + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -362,7 +368,8 @@ extern "C" int adm_resample(const adm_bf16* in, const float* aff_a, const float*
 #define LAUNCH(M, A) hipLaunchKernelGGL((resample_kernel<M, A>), dim3(blocks), dim3(256), 0, s, in, aff_a, aff_b, out, n, h, w, c)
   if (mode == 1) { if (act) LAUNCH(1, true); else LAUNCH(1, false); }
   else if (mode == 2) { if (act) LAUNCH(2, true); else LAUNCH(2, false); }
-  else           { if (act) LAUNCH(3, true); else LAUNCH(3, false); }
+  else if (mode == 3) { if (act) LAUNCH(3, true); else LAUNCH(3, false); }
+  else           LAUNCH(4, false);
 #undef LAUNCH
   return adm_check_launch("adm_resample");
 }

@@ -161,8 +161,8 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
     fused0 = getattr(x0, "_adm_stats", None)
     fused1 = getattr(x1, "_adm_stats", None) if x1 is not None else None
     if add is not None:
-        if x1 is not None or film is not None or want_stats:
-            raise AdmError("gn_affine(add=...) takes one source, no FiLM and keeps no statistics")
+        if x1 is not None or film is not None:
+            raise AdmError("gn_affine(add=...) takes one source and no FiLM")
         if add.dtype != torch.float32 or add.shape != (n, c) or add.stride(1) != 1:
             raise AdmError("add must be float32 [N, C] with unit channel stride")
         if USE_FUSED_STATS and fused0 is not None:
@@ -172,9 +172,9 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
             part = torch.empty((n, slabs, c, 2), dtype=torch.float32, device=x0.device)
             check(lib.adm_gn_partial(_ptr(x0, x0.dtype, "x0"), c0, None, 0, _ptr(part), n, hw, slabs, _stream()), "adm_gn_partial")
         check(lib.adm_gn_finalize_add(_ptr(part), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
-                                      add.data_ptr(), add.stride(0), _ptr(a), _ptr(b), n, c, hw, slabs, eps, _stream()),
+                                      add.data_ptr(), add.stride(0), _ptr(a), _ptr(b), _ptr(stats), n, c, hw, slabs, eps, _stream()),
               "adm_gn_finalize_add")
-        return a, b
+        return (a, b, stats) if want_stats else (a, b)
     if USE_FUSED_STATS and fused0 is not None and (x1 is None or fused1 is not None):
         # the producing conv already accumulated sum / sum-of-squares of this tensor in its epilogue
         p1, s1 = (fused1 if fused1 is not None else (None, 0))
@@ -196,11 +196,11 @@ def gn_affine(x0, gamma, beta, x1=None, film=None, film_stride=0, partial=None, 
 
 
 def resample(x, mode: str, aff=None):
-    """mode 'down' = AvgPool2d(2), 'up' = nearest x2, 'stride2' = every second pixel; aff=(a, b) applies
-    SiLU(a*x+b) first."""
+    """mode 'down' = AvgPool2d(2), 'up' = nearest x2, 'stride2' = every second pixel, 'zero2' = zero-insert x2 (out[2y][2x] = x[y][x]:
+    what a stride-2 conv's backward-data conv reads); aff=(a, b) applies SiLU(a*x+b) first."""
     n, h, w, c = x.shape
-    m = {"down": 1, "up": 2, "stride2": 3}[mode]
-    oh, ow = (h * 2, w * 2) if m == 2 else (h // 2, w // 2)
+    m = {"down": 1, "up": 2, "stride2": 3, "zero2": 4}[mode]
+    oh, ow = (h * 2, w * 2) if m in (2, 4) else (h // 2, w // 2)
     out = torch.empty((n, oh, ow, c), dtype=x.dtype, device=x.device)
     a, b = aff if aff is not None else (None, None)
     check(_L(x).adm_resample(_ptr(x, x.dtype, "x"), _ptr(a, torch.float32), _ptr(b, torch.float32), _ptr(out),
@@ -491,8 +491,10 @@ def attention_bwd(qkv, out, dout, lse, heads: int, new_order: bool):
     return dqkv
 
 
-def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=False, partial=None):
+def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=False, partial=None, norm_add=None):
     """Backward of y = act(a*x+b) (GroupNorm(+FiLM)(+SiLU)): returns dx bf16 NHWC (+ add).
+
+    norm_add: fp32 [N, C] e of a layer that normalised x + e[:, :, None, None] (gn_affine(add=e, want_stats=True)).
 
     partial: the producing backward-data conv already wrote dz = dy * SiLU'(a x + b) and its (sum dz, sum dz x) slabs
     (conv(..., gnb=(x, aff)): adm_conv_args.prologue == 3) -- `dy` is then that dz and the partial pass is skipped."""
@@ -513,8 +515,11 @@ def gn_bwd(x, dy, aff, stats, silu: bool, dy_half=False, add=None, add_half=Fals
             raise AdmError("gn_bwd(partial=...): same-resolution dz and [n, slabs, c, 2] sums expected")
         slabs = partial.shape[1]
         silu = False   # the SiLU derivative is already in dz
-    check(lib.adm_gn_bwd_finalize(_ptr(partial), _ptr(a), _ptr(stats, torch.float32, "stats"), _ptr(k1), _ptr(k0),
-                                  n, c, hw, slabs, _stream()), "adm_gn_bwd_finalize")
+    if norm_add is not None and (norm_add.dtype != torch.float32 or norm_add.shape != (n, c) or norm_add.stride(1) != 1):
+        raise AdmError("norm_add must be float32 [N, C] with unit channel stride")
+    check(lib.adm_gn_bwd_finalize(_ptr(partial), _ptr(a), _ptr(stats, torch.float32, "stats"),
+                                  None if norm_add is None else norm_add.data_ptr(), 0 if norm_add is None else norm_add.stride(0),
+                                  _ptr(k1), _ptr(k0), n, c, hw, slabs, _stream()), "adm_gn_bwd_finalize")
     out = torch.empty_like(x)
     check(lib.adm_gn_bwd_apply(_ptr(x), _ptr(dy, x.dtype, "dy"), _ptr(a), _ptr(b), _ptr(k1), _ptr(k0), _ptr(add, x.dtype, "add"),
                                _ptr(out), n, h, w, c, int(silu), int(dy_half), int(add_half), _stream()),
@@ -572,6 +577,57 @@ def pool_prep_bwd(dtok, hh: int, ww: int):
     check(_L(dtok).adm_pool_prep_bwd(_ptr(dtok, dtok.dtype, "dtok"), _ptr(dact), n, hh * ww, c, tpad, _stream()),
           "adm_pool_prep_bwd")
     return dact
+
+
+# ------------------------------------------------------------------ the classifier's other heads (csrc/adm_clfhead.hip)
+def channel_mean(h, aff=None, out=None, col: int = 0):
+    """mean over the pixels of SiLU(a*h + b) (aff given) or of h itself -> fp32 [N, C], or into out[:, col:col + C]."""
+    n, hh, ww, c = h.shape
+    if out is None:
+        out, col = torch.empty((n, c), dtype=torch.float32, device=h.device), 0
+    if out.dtype != torch.float32 or out.stride(1) != 1 or col + c > out.shape[1]:
+        raise AdmError("channel_mean: out must be float32 [N, >= col + C] with unit column stride")
+    a, b = aff if aff is not None else (None, None)
+    check(_L(h).adm_channel_mean(_ptr(h, h.dtype, "h"), _ptr(a, torch.float32), _ptr(b, torch.float32),
+                                 out.data_ptr() + 4 * col, out.stride(0), n, hh * ww, c, _stream()), "adm_channel_mean")
+    return out
+
+
+def bcast_add(v, shape, dtype, scale: float, add=None, col: int = 0):
+    """16-bit NHWC [n, h, w, c] = (add or 0) + v[:, col:col + c, None, None] * scale (the backward of a pixel mean)."""
+    n, hh, ww, c = shape
+    if v.dtype != torch.float32 or v.stride(1) != 1 or v.shape[0] != n or col + c > v.shape[1]:
+        raise AdmError("bcast_add: v must be float32 [N, >= col + C] with unit column stride")
+    out = torch.empty(shape, dtype=dtype, device=v.device)
+    check(_L(out).adm_bcast_add(v.data_ptr() + 4 * col, v.stride(0), float(scale), _ptr(add, dtype, "add"), _ptr(out), n, hh * ww, c,
+                                _stream()), "adm_bcast_add")
+    return out
+
+
+def vec_act(x, mode: str, dy=None):
+    """fp32 vectors: act(x), or dy * act'(x) with dy; mode 'silu' | 'relu'."""
+    out = torch.empty_like(x)
+    check(_lib.load().adm_vec_act(_ptr(x, torch.float32, "x"), _ptr(dy, torch.float32, "dy"), _ptr(out), x.numel(),
+                                  {"silu": 1, "relu": 2}[mode], _stream()), "adm_vec_act")
+    return out
+
+
+def vec_gn(x, gamma, beta, eps: float = GN_EPS):
+    """GroupNorm32(32, C) of fp32 [N, C] rows -> (y, stats [N, 32, 2])."""
+    n, c = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((n, 32, 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().adm_vec_gn(_ptr(x, torch.float32, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(beta, torch.float32, "beta"),
+                                 _ptr(y), _ptr(stats), n, c, float(eps), _stream()), "adm_vec_gn")
+    return y, stats
+
+
+def vec_gn_bwd(x, gamma, stats, dz):
+    n, c = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().adm_vec_gn_bwd(_ptr(x, torch.float32, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(stats, torch.float32, "stats"),
+                                     _ptr(dz, torch.float32, "dz"), _ptr(dx), n, c, _stream()), "adm_vec_gn_bwd")
+    return dx
 
 
 def pack_conv_weight_bwd(w, dtype=BF16):

@@ -196,10 +196,6 @@ class AdmNet(HipModule):
         self.num_classes = plan.num_classes
         if plan.dynamic:
             self.layer_num = plan.layer_num
-        for b in plan.all_blocks():
-            if isinstance(b, ResBlockSpec) and not b.scale_shift and self.with_backward:
-                raise NotImplementedError("classifier_use_scale_shift_norm=False: the backward-data network differentiates the FiLM form "
-                                          "only (create_classifier's default and every reference launch script use it)")
 
     with_backward = False  # classifier: also pack the backward-data weight images
     grad_scale = 1.0       # classifier with an fp16 backward network: static power-of-two scale of d(logits) (classifier.py)
@@ -348,6 +344,9 @@ class AdmNet(HipModule):
                     if b.has_skip_conv:
                         d["ws_bwd"] = pack_bwd(P[f"{p}.skip_connection.weight"])
                     zmax = max(zmax, b.cin, b.cout)
+                elif isinstance(b, ResampleSpec):   # Downsample conv of a classifier_resblock_updown=False classifier
+                    d["w_bwd"] = pack_bwd(P[f"{p}.op.weight"])
+                    zmax = max(zmax, b.channels)
                 elif isinstance(b, AttnSpec):
                     d["wqkv_bwd"] = pack_bwd(P[f"{p}.qkv.weight"])
                     d["wproj_bwd"] = pack_bwd(P[f"{p}.proj_out.weight"])
@@ -395,10 +394,14 @@ class AdmNet(HipModule):
             xs, xs1 = x0, x1
         off = pr.film_off[s.prefix]
         if tape is not None:
-            a2, b2, st2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total,
-                                        want_stats=True)
+            add2 = None
+            if s.scale_shift:
+                a2, b2, st2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total, want_stats=True)
+            else:   # out_layers(h + emb_out): the backward pass needs e to correct the stored-h sums (ops.gn_bwd(norm_add=))
+                add2 = film[:, off:off + s.cout]
+                a2, b2, st2 = ops.gn_affine(h, d["g2"], d["b2"], add=add2, want_stats=True)
             aff2 = (a2, b2)
-            tape.append(("res", s, dict(x=x0, aff1=aff1, st1=st1, h1=h, aff2=aff2, st2=st2)))
+            tape.append(("res", s, dict(x=x0, aff1=aff1, st1=st1, h1=h, aff2=aff2, st2=st2, add2=add2)))
         elif not s.scale_shift:
             # use_scale_shift_norm=False (reference unet.py:251-254): out_layers(h + emb_out).  h + e is never written: the statistics
             # of x + e[n, c] follow from the conv epilogue's per-channel sums and e folds into the next conv's prologue affine
@@ -453,6 +456,8 @@ class AdmNet(HipModule):
                 h = self._resblock(pr, blk, h, skip if first else None, film, blk.layer_id in skip_ids, tape)
             elif isinstance(blk, ResampleSpec):
                 h = self._resample(pr, blk, h)
+                if tape is not None:
+                    tape.append(("down", blk, {}))
             else:
                 h = self._attention(pr, blk, h, blk.layer_id in skip_ids, tape)
             first = False

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 6   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu */
+#define ADM_ABI_VERSION 7   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu;
+                               7: adm_gn_finalize_add gained stats, adm_gn_bwd_finalize gained add / add_stride; the classifier's other heads */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -125,7 +126,10 @@ int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const float* par
 /* h_upd / x_upd of an up/down ResBlock (unet.py:190-195, 237-242):
  * out = resample(act(a*in + b)), act = SiLU when aff_a != NULL, identity copy otherwise.
  * mode 1 = AvgPool2d(2) (H,W -> H/2,W/2), mode 2 = nearest x2, mode 3 = every second pixel
- * (turns a stride-1 3x3 conv into the stride-2 Downsample of the latent UNet).             */
+ * (turns a stride-1 3x3 conv into the stride-2 Downsample of the latent UNet), mode 4 = zero-insert x2
+ * (out[2y][2x] = in[y][x], 0 elsewhere, no affine: the backward-data conv of a stride-2 3x3 conv -- the classifier's
+ * Downsample with classifier_resblock_updown = False, unet.py:115-140 -- is the stride-1 conv with transposed, flipped
+ * weights over this tensor).                                                                */
 int adm_resample(const adm_bf16* in, const float* aff_a, const float* aff_b, adm_bf16* out,
                  int n, int h, int w, int c, int mode, void* stream);
 
@@ -232,7 +236,8 @@ int adm_geglu(const adm_bf16* u, adm_bf16* out, int64_t rows, int inner, void* s
  * h = h + emb_out; h = out_layers(h)): statistics of x + e are derived from the partial sums of x, and
  * a = rstd*gamma, b = beta + (e - mean)*rstd*gamma.  add fp32 [N][add_stride].                                   */
 int adm_gn_finalize_add(const float* partial, const float* gamma, const float* beta, const float* add, int add_stride,
-                        float* aff_a, float* aff_b, int n, int c, int hw, int slabs, float eps, void* stream);
+                        float* aff_a, float* aff_b, float* stats /* nullable: (mean, rstd) of x + e per (image, group), for the backward pass */,
+                        int n, int c, int hw, int slabs, float eps, void* stream);
 
 /* One DDIM / PLMS update of the latent samplers (ddim.py:165-203, plms.py:195-258), fp32 tensors of numel elements:
  *   e     = eps_uncond ? eps_uncond + cfg_scale*(eps_cond - eps_uncond) : eps_cond        (written to e_out if given)
@@ -274,8 +279,10 @@ int adm_attention_bwd(const adm_bf16* qkv, const adm_bf16* out, const adm_bf16* 
 int adm_gn_bwd_partial(const adm_bf16* x, const adm_bf16* dy, const float* aff_a, const float* aff_b,
                        float* partial, int n, int h, int w, int c, int slabs, int silu, int dy_half,
                        void* stream);
-int adm_gn_bwd_finalize(const float* partial, const float* aff_a, const float* stats, float* k1, float* k0,
-                        int n, int c, int hw, int slabs, void* stream);
+/* add (nullable, fp32 [N][add_stride]): the layer normalised x + add[n, c] (adm_gn_finalize_add) while x is what was stored and
+ * summed; the sums are corrected (sum dz (x + e) = sum dz x + e sum dz) and k0 absorbs k1 * e, so adm_gn_bwd_apply runs unchanged. */
+int adm_gn_bwd_finalize(const float* partial, const float* aff_a, const float* stats, const float* add, int add_stride,
+                        float* k1, float* k0, int n, int c, int hw, int slabs, void* stream);
 int adm_gn_bwd_apply(const adm_bf16* x, const adm_bf16* dy, const float* aff_a, const float* aff_b,
                      const float* k1, const float* k0, const adm_bf16* add, adm_bf16* out,
                      int n, int h, int w, int c, int silu, int dy_half, int add_half, void* stream);
@@ -343,6 +350,23 @@ int adm_global_avgpool_f32(const adm_bf16* in, float* out, int n, int hw, int c,
  * 2: fp32 NHWC.  half_pixel 1: torch bilinear, align_corners=False (pytorch_fid); 0: TensorFlow-1 ResizeBilinear.          */
 int adm_resize_bilinear(const void* in, adm_bf16* out, int n, int h, int w, int oh, int ow, int cpad, int kind, int half_pixel,
                         float scale, float shift, void* stream);
+
+/* ---------------------------------------------------------------- the classifier's other heads (A9 variants)
+ * EncoderUNetModel pool = "adaptive" | "spatial" | "spatial_v2" (guided_diffusion/unet.py:826-856, 880-896); create_classifier's
+ * default and every launch script use "attention" (above).  The Linear layers between these are adm_linear_f32.
+ *   adm_channel_mean  out[n][ch] = mean_p act(h[n][p][ch]), act = SiLU(a h + b) with the affine (adaptive: GN -> SiLU -> AvgPool),
+ *                     identity without (spatial: h.mean(dim=(2, 3)) of every block, written at a column offset of the feature row)
+ *   adm_bcast_add     out[n][p][ch] = (add ? add[n][p][ch] : 0) + v[n][ch] * scale: the backward of a pixel mean (scale = 1 / HW)
+ *                     accumulated into the gradient that flows through the same tensor
+ *   adm_vec_act       mode 1 SiLU, 2 ReLU on fp32 vectors: out = act(x), or with dy: out = dy * act'(x)
+ *   adm_vec_gn(_bwd)  GroupNorm32(32, C) of fp32 [N][C] rows (spatial_v2's normalization(2048): no spatial axis), stats fp32
+ *                     [N][32][2] = (mean, rstd); backward-data dx from dz = d(loss)/d(y)                                    */
+int adm_channel_mean(const adm_bf16* h, const float* aff_a, const float* aff_b, float* out, int out_stride, int n, int hw, int c,
+                     void* stream);
+int adm_bcast_add(const float* v, int v_stride, float scale, const adm_bf16* add, adm_bf16* out, int n, int hw, int c, void* stream);
+int adm_vec_act(const float* x, const float* dy, float* out, int64_t items, int mode, void* stream);
+int adm_vec_gn(const float* x, const float* gamma, const float* beta, float* y, float* stats, int n, int c, float eps, void* stream);
+int adm_vec_gn_bwd(const float* x, const float* gamma, const float* stats, const float* dz, float* dx, int n, int c, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,78 @@ def test_gn_silu_backward_matches_autograd(ops, silu, film, half):
     assert rel(got, ref) < 8e-3, rel(got, ref)
 
 
+def test_gn_backward_of_a_layer_that_normalised_x_plus_embedding(ops):
+    """use_scale_shift_norm=False (reference unet.py:251-254: out_layers(h + emb_out)): h + e is never stored; the forward affine
+    comes from adm_gn_finalize_add, and the backward sums over the STORED h are corrected in adm_gn_bwd_finalize (norm_add)."""
+    n, c, hw = 3, 64, 16
+    x = bf(rnd((n, c, hw, hw), 1, 1.5) + 0.2).requires_grad_(True)
+    e = rnd((n, c), 8, 0.7)
+    gamma, beta = 1 + 0.2 * rnd((c,), 2), 0.1 * rnd((c,), 3)
+    y = F.silu(F.group_norm(x + e[:, :, None, None], 32, gamma, beta, eps=1e-5))
+    dy = bf(rnd((n, c, hw, hw), 5))
+    (ref,) = torch.autograd.grad(y, x, dy)
+    xd = nhwc_dev(x.detach())
+    wide = torch.zeros(n, 3 * c, device=DEV)      # e as a strided view, like the slice of the FiLM matrix the model passes
+    wide[:, c:2 * c] = e.to(DEV)
+    ed = wide[:, c:2 * c]
+    a, b, st = ops.gn_affine(xd, gamma.to(DEV), beta.to(DEV), add=ed, want_stats=True)
+    fwd = nchw_cpu(ops.resample(ops.resample(xd, "up", (a, b)), "down"))     # SiLU(a x + b) through two existing passes
+    assert rel(fwd, y.detach()) < 6e-3
+    got = nchw_cpu(ops.gn_bwd(xd, nhwc_dev(dy), (a, b), st, silu=True, norm_add=ed))
+    assert rel(got, ref) < 8e-3, rel(got, ref)
+    wrong = nchw_cpu(ops.gn_bwd(xd, nhwc_dev(dy), (a, b), st, silu=True))     # without the correction the sums are those of another layer
+    assert rel(wrong, ref) > 1.5e-2 and rel(wrong, ref) > 2.5 * rel(got, ref)
+
+
+def test_stride2_conv_backward_data_through_zero_insertion(ops):
+    """Downsample of a classifier_resblock_updown=False classifier (reference unet.py:115-140: 3x3 stride-2 conv): its backward-data
+    conv = the stride-1 conv with transposed, flipped weights over the zero-inserted gradient (adm_resample mode 4)."""
+    n, c, hw = 2, 64, 16
+    x = bf(rnd((n, c, hw, hw), 1)).requires_grad_(True)
+    w = bf(rnd((c, c, 3, 3), 2, (c * 9) ** -0.5))
+    dy = bf(rnd((n, c, hw // 2, hw // 2), 3))
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, stride=2, padding=1), x, dy)
+    z = ops.resample(nhwc_dev(dy), "zero2")
+    assert z.shape == (n, hw, hw, c) and torch.equal(z[:, ::2, ::2], nhwc_dev(dy)) and float(z[:, 1::2].abs().max()) == 0 \
+        and float(z[:, :, 1::2].abs().max()) == 0
+    got = nchw_cpu(ops.conv(z, ops.pack_conv_weight_bwd(w.to(DEV)), torch.zeros(c, device=DEV), c, 9))
+    assert rel(got, ref) < 4e-3, rel(got, ref)
+
+
+def test_pool_head_kernels_match_torch(ops):
+    """csrc/adm_clfhead.hip: channel means (with / without the GN + SiLU affine, into a column window), their backward broadcast,
+    ReLU / SiLU and GroupNorm32 on fp32 vectors with their backward-data forms."""
+    n, c, hw = 3, 96, 8
+    x = bf(rnd((n, c, hw, hw), 1))
+    a, b = 1 + 0.2 * rnd((n, c), 2), 0.1 * rnd((n, c), 3)
+    xd = nhwc_dev(x)
+    feat = torch.full((n, 40 + c + 8), 7.0, device=DEV)
+    ops.channel_mean(xd, out=feat, col=40)
+    torch.testing.assert_close(feat[:, 40:40 + c].cpu(), x.mean(dim=(2, 3)), rtol=1e-5, atol=1e-6)
+    assert float((feat[:, :40] - 7).abs().max()) == 0 and float((feat[:, 40 + c:] - 7).abs().max()) == 0
+    m = ops.channel_mean(xd, (a.to(DEV), b.to(DEV))).cpu()
+    torch.testing.assert_close(m, F.silu(a[:, :, None, None] * x + b[:, :, None, None]).mean(dim=(2, 3)), rtol=1e-4, atol=1e-5)
+    v = rnd((n, 40 + c), 4)
+    g0 = bf(rnd((n, c, hw, hw), 5))
+    got = nchw_cpu(ops.bcast_add(v.to(DEV), (n, hw, hw, c), torch.bfloat16, 1.0 / 64, add=nhwc_dev(g0), col=40))
+    torch.testing.assert_close(got, bf(g0 + v[:, 40:, None, None] / 64), rtol=0, atol=0)
+    got = nchw_cpu(ops.bcast_add(v.to(DEV), (n, hw, hw, c), torch.bfloat16, 0.5, col=40))
+    torch.testing.assert_close(got, bf((v[:, 40:, None, None] * 0.5).expand(n, c, hw, hw)), rtol=0, atol=0)
+    z, dy = rnd((5, 2048), 6, 2.0), rnd((5, 2048), 7)
+    for mode, fn in (("relu", F.relu), ("silu", F.silu)):
+        zz = z.clone().requires_grad_(True)
+        (ref,) = torch.autograd.grad(fn(zz), zz, dy)
+        torch.testing.assert_close(ops.vec_act(z.to(DEV), mode).cpu(), fn(z), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(ops.vec_act(z.to(DEV), mode, dy=dy.to(DEV)).cpu(), ref, rtol=1e-5, atol=1e-6)
+    gamma, beta = 1 + 0.2 * rnd((2048,), 8), 0.1 * rnd((2048,), 9)
+    zz = z.clone().requires_grad_(True)
+    y = F.group_norm(zz, 32, gamma, beta, eps=1e-5)
+    (ref,) = torch.autograd.grad(y, zz, dy)
+    yd, st = ops.vec_gn(z.to(DEV), gamma.to(DEV), beta.to(DEV))
+    torch.testing.assert_close(yd.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ops.vec_gn_bwd(z.to(DEV), gamma.to(DEV), st, dy.to(DEV)).cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
 def test_conv_backward_data_weights(ops):
     for cin, cout, k in ((64, 96, 3), (32, 64, 1), (128, 3, 3)):
         x = bf(rnd((2, cin, 16, 16), 1)).requires_grad_(True)

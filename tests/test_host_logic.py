@@ -94,8 +94,10 @@ def test_factory_signatures_defaults_and_state_dict_layout():
     assert clf.state_dict()["out.2.positional_embedding"].shape == (256, 65)
     m2, _ = create_model_and_diffusion(**{**d, "resblock_updown": False})   # conv Downsample / Upsample: built since round 3 (tests/test_variants.py)
     assert any(k.endswith(".op.weight") for k in m2.state_dict())
-    with pytest.raises(NotImplementedError):   # ... but not for the classifier, whose backward network has no stride-2 conv
-        create_classifier(**{**classifier_defaults(), "classifier_width": 64, "classifier_depth": 1, "classifier_resblock_updown": False})
+    c2 = create_classifier(**{**classifier_defaults(), "classifier_width": 64, "classifier_depth": 1, "classifier_resblock_updown": False})
+    assert any(k.endswith(".op.weight") for k in c2.state_dict())   # ... and for the classifier (late round 3: zero-insert + flipped conv backward)
+    with pytest.raises(NotImplementedError):
+        create_classifier(**{**classifier_defaults(), "classifier_width": 64, "classifier_depth": 1, "classifier_pool": "max"})
 
 
 def test_hot_path_refuses_to_run_without_a_gpu():
