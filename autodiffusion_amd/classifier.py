@@ -12,6 +12,10 @@ every conv's backward-data is the same fused MFMA conv kernel with transposed, t
 GroupNorm(+FiLM)+SiLU, attention and the attention pool have dedicated backward kernels
 (csrc/adm_backward.hip, csrc/adm_attention_bwd.hip).  Activations and gradients between kernels are
 bf16 NHWC; accumulation, GroupNorm statistics, softmax and the logits are fp32.
+
+Every ``create_classifier`` flag is built: the pools "adaptive" / "spatial" / "spatial_v2" (unet.py:826-856, 880-896;
+csrc/adm_clfhead.hip), ``classifier_use_scale_shift_norm=False`` (GroupNorm of h + emb with only h stored) and
+``classifier_resblock_updown=False`` (the stride-2 Downsample conv: backward = zero-insert + transposed, flipped conv).
 """
 from __future__ import annotations
 
