@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")
 # the same kernels built with IEEE half as the 16-bit element type (csrc/adm_common.h, -DADM_ACT_F16): the reference's own
 # torso precision (use_fp16=True); selected per tensor dtype by ops.py, per model by `torso="fp16"` / ADM_TORSO=fp16
 LIB_PATH_F16 = os.environ.get("ADM_HIP_LIB_F16") or os.path.join(_HERE, "libadm_hip_f16.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class AdmError(RuntimeError):
@@ -48,6 +48,7 @@ class ConvArgs(C.Structure):
         ("variant", C.c_int32), ("out_stats", C.c_void_p), ("w_packed32", C.c_void_p),
         ("in_up", C.c_int32), ("res_up", C.c_int32), ("ksplit", C.c_int32), ("ws", C.c_void_p),
         ("up_phase", C.c_int32), ("geglu", C.c_int32),
+        ("fold0", C.c_void_p), ("fold1", C.c_void_p), ("fc0", C.c_int32), ("fc1", C.c_int32),
     ]
 
 

@@ -84,6 +84,11 @@ struct ConvK {
   // and phase p's packed weights start phase_bytes * p into `w` (the tile list is 4 x as long: small batches still fill the CUs)
   int nph, nbp;
   unsigned phase_bytes;
+  // skip-connection fold (PROX = 4; adm_conv_args.fold0): after the nine-tap K loop over the GroupNorm + SiLU input, (FC0 + FC1) / 32
+  // one-tap, raw-prologue K-steps over the ResBlock's INPUT (fold0 | fold1, same map) with the skip_connection's 1x1 weights, which
+  // follow the 3x3 weights in `w` (K-step index chunks * 9 + j): out = conv3x3(act(GN(h))) + conv1x1(x) + (bias3 + bias1)
+  const uint16_t* f0; const uint16_t* f1;
+  int FC0, FC1;
 };
 
 // output-statistics slabs per tile: a 128-pixel tile is two 8x8 images (or two halves of one image)
@@ -162,8 +167,9 @@ conv_kernel(const ConvK p) {
   // backward of the layer in front (adm_conv_args.prologue == 3): with x = that layer's input (`res`) and its affine (a, b),
   // out = dz = acc * SiLU'(a x + b), statistics = (sum dz, sum dz * x) per (image, slab, channel) -- the partial sums the
   // separate adm_gn_bwd_partial pass would re-read x and dy for
-  constexpr int PRO = PROX == 3 ? 0 : PROX;
+  constexpr int PRO = PROX == 3 ? 0 : (PROX == 4 ? 2 : PROX);
   constexpr bool GNB = PROX == 3;
+  constexpr bool FOLD = PROX == 4;   // GN + SiLU prologue, then the ResBlock's skip_connection as extra one-tap K-steps (ConvK::f0)
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = WM * TM * 16;
   constexpr int BN = WN * TN * 16;
@@ -250,6 +256,7 @@ conv_kernel(const ConvK p) {
   [[maybe_unused]] int ph = p.slab_off;   // up-conv phase of the current tile (fixed per launch unless p.nph == 4)
   int sp = 0, cb = 0, ce = chunks;   // K split of the tile: chunks [cb, ce)
   __amdgpu_buffer_rsrc_t rs0 = rsw, rs1 = rsw;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rs2 = rsw, rs3 = rsw;   // FOLD: the skip_connection's sources
   int pixrel[PASSES];      // pixel index relative to img0, or -1 (zero padding / beyond the batch / spare slot)
   // weight fragments go straight from the packed image (L2-resident, fragment-ordered: one 1 KB
   // coalesced run per wave-load) into registers -- no LDS, no per-tap barrier
@@ -289,6 +296,11 @@ conv_kernel(const ConvK p) {
     rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (long long)img0 * Hs * Ws * p.C0), 0, nimg * Hs * Ws * p.C0 * 2, 0x00020000);
     rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C1 ? p.in1 + (long long)img0 * HWimg * p.C1 : p.in0), 0,
                                             p.C1 ? nimg * HWimg * p.C1 * 2 : 0, 0x00020000);
+    if constexpr (FOLD) {
+      rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.f0 + (long long)img0 * HWimg * p.FC0), 0, nimg * HWimg * p.FC0 * 2, 0x00020000);
+      rs3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.FC1 ? p.f1 + (long long)img0 * HWimg * p.FC1 : p.f0), 0,
+                                              p.FC1 ? nimg * HWimg * p.FC1 * 2 : 0, 0x00020000);
+    }
     // the halo pixel of each pass is recomputed per tile from an opaque copy of the thread index: nothing
     // per-lane has to survive the K loop (it runs at the VGPR cap; a reload from scratch costs a dependent
     // memory round trip here).  Divisions by the patch size / width are multiplications by host-made
@@ -346,6 +358,18 @@ conv_kernel(const ConvK p) {
     const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
     const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
     return bufload16(rs, voff, 0);
+  };
+  // FOLD: segment `ps` of chunk k of the skip_connection's input (same halo geometry: only its centre tap is used), and its raw park
+  [[maybe_unused]] auto fold_load = [&](int k, int ps) -> uint4 {
+    const int f0chunks = p.FC0 / KCS;
+    const bool first = k < f0chunks;
+    const int cs = first ? p.FC0 : p.FC1, co = (first ? k : k - f0chunks) * KCS;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs2 : rs3;
+    const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
+    return bufload16(rs, voff, 0);
+  };
+  [[maybe_unused]] auto raw_write = [&](uint4 v, int ps, int buf) {
+    *reinterpret_cast<uint4*>(halo + buf * Lds::HB + ps * (NT / SEGP) * ROWB + hslot) = v;
   };
   // affine table of stage c: threads < TI * KCS/2 fetch one float4 of a (parts < KCS/4) or b
   constexpr int APT = KCS / 2;             // threads per image of the tile
@@ -623,8 +647,9 @@ conv_kernel(const ConvK p) {
       chunk1(ce - 1, std::false_type{});
     } else if constexpr (T3) {
       // weight ring of 3 K-steps (9 % 3 == 0: the ring slot of tap t is t % 3 in every chunk)
-      auto chunk = [&](int c, auto more_) {
+      auto chunk = [&](int c, auto more_, auto rawnext_) {
         constexpr bool MORE = decltype(more_)::value;
+        constexpr bool RAWNEXT = decltype(rawnext_)::value;   // FOLD: the chunk staged for the next stage is the skip path's first (raw)
         const int hb = c & 1;
         const int step0 = c * 9;
         uint4 hprev = make_uint4(0, 0, 0, 0);
@@ -635,7 +660,7 @@ conv_kernel(const ConvK p) {
           // transformed and parked in the other halo buffer
           uint4 hcur = make_uint4(0, 0, 0, 0);
           if constexpr (MORE) {
-            if (t < PASSES) hcur = halo_load(c + 1, t);
+            if (t < PASSES) hcur = RAWNEXT ? fold_load(0, t) : halo_load(c + 1, t);
           }
           if (MORE || t + 2 < 9) load_w(step0 + t + 2, wr[(t + 2) % 3]);
           // small maps (128-pixel tiles): a mid-chunk rendezvous keeps the waves that share weight fragments
@@ -648,7 +673,10 @@ conv_kernel(const ConvK p) {
             if (t == 7 && c + 2 < ce) affine_park(affv, hb);
           }
           if constexpr (MORE) {
-            if (t >= 1 && t - 1 < PASSES) halo_write(hprev, t - 1, hb ^ 1);
+            if (t >= 1 && t - 1 < PASSES) {
+              if constexpr (RAWNEXT) raw_write(hprev, t - 1, hb ^ 1);
+              else halo_write(hprev, t - 1, hb ^ 1);
+            }
           }
           hprev = hcur;
           if (!UPPH || (((0x1b << ((ph >> 1) * 3 + (ph & 1))) >> t) & 1))   // up-conv phase: 5 of the 9 taps carry zero weights (wave-uniform skip)
@@ -656,8 +684,41 @@ conv_kernel(const ConvK p) {
         }
         __syncthreads();  // halo[hb^1] and abuf[hb] complete; every wave is done reading halo[hb]
       };
-      for (int c = cb; c + 1 < ce; ++c) chunk(c, std::true_type{});
-      chunk(ce - 1, std::false_type{});
+      for (int c = cb; c + 1 < ce; ++c) chunk(c, std::true_type{}, std::false_type{});
+      if constexpr (!FOLD) {
+        chunk(ce - 1, std::false_type{}, std::false_type{});
+      } else {
+        // the last nine-tap chunk stages skip chunk 0 (raw) into the other halo buffer and its taps 7, 8 fetch the skip path's
+        // first two weight K-steps (they follow the 3x3 weights: ring slots 0, 1 again since 9 % 3 == 0)
+        chunk(ce - 1, std::true_type{}, std::true_type{});
+        // ---- the skip_connection as one-tap K-steps: activations two chunks ahead in registers (ring of 2), weights two K-steps
+        // ahead (ring of 3), one barrier per step like the 1x1 loop; only the centre tap's fragment rows are read
+        const int fch = (p.FC0 + p.FC1) / KCS, flast = fch - 1;
+        const int fstep0 = chunks * 9;
+        const unsigned char* const hc = halo + (HW2 + 1) * ROWB;     // centre tap
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = fold_load(min(1, flast), ps);
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) ring[0][ps] = fold_load(min(2, flast), ps);
+        auto fbody = [&](int j, auto s_) {
+          constexpr int S = decltype(s_)::value;     // j % 6: ring slots (j + 1) & 1 (activations), j % 3 (weights)
+          if (j > flast) return;
+          const int buf = (ce + j) & 1;
+          load_w(fstep0 + min(j + 2, flast), wr[(S + 2) % 3]);
+          mfma_tap(hc + buf * Lds::HB, wr[S % 3]);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) raw_write(ring[(S + 1) & 1][ps], ps, buf ^ 1);
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) ring[(S + 1) & 1][ps] = fold_load(min(j + 3, flast), ps);
+          __syncthreads();
+        };
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+        using J3 = std::integral_constant<int, 3>; using J4 = std::integral_constant<int, 4>; using J5 = std::integral_constant<int, 5>;
+        for (int j0 = 0; j0 < fch; j0 += 6) {
+          fbody(j0, J0{}); fbody(j0 + 1, J1{}); fbody(j0 + 2, J2{});
+          fbody(j0 + 3, J3{}); fbody(j0 + 4, J4{}); fbody(j0 + 5, J5{});
+        }
+      }
     } else {
       // 1x1: a stage is KS K-steps (KS*TM*TN MFMAs per wave) and ends in the loop's only barrier, so HBM/L2
       // latency must be covered by depth, not by taps: activation segments are fetched 2 stages ahead (register
@@ -1379,6 +1440,9 @@ int launch_conv(const ConvK& k, int prologue, int m_tiles, hipStream_t s) {
     case 3:   // GroupNorm-backward epilogue: 3x3 backward-data convs on the 256-pixel 8-wave tiles only
       if constexpr (TAPS == 9 && HALO == 324 && WN == 4 && !COLD) return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 3, KS, COLD>(k, m_tiles, s);
       else ADM_FAIL(ADM_E_SHAPE, "adm_conv: prologue 3 (GroupNorm-backward epilogue) needs a 3x3 conv on a map >= 16x16");
+    case 4:   // GN + SiLU prologue with the skip_connection folded in as one-tap K-steps: the same tiles
+      if constexpr (TAPS == 9 && WN == 4 && !COLD) return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 4, KS, COLD>(k, m_tiles, s);
+      else ADM_FAIL(ADM_E_SHAPE, "adm_conv: the skip-connection fold needs a 3x3 conv on the 8-wave tiles");
     default: return launch_conv_p<WM, WN, TM, TN, OCC, TAPS, HALO, 2, KS, COLD>(k, m_tiles, s);
   }
 }
@@ -1582,6 +1646,19 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   }
   k.ntiles16 = (a->cout + 15) / 16;
   k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * a->taps * k.ntiles16 * 1024);
+  int prologue = a->prologue;
+  if (a->fold0) {
+    // ResBlock out_layers conv + skip_connection in one K loop (reference unet.py:216-222, 256: `self.skip_connection(x) + h`)
+    ADM_REQUIRE(a->taps == 9 && a->prologue == 2 && a->out_mode == 0 && !a->res && !a->in_up && !a->res_up && !a->up_phase && a->ksplit <= 1 &&
+                ((a->h >= 16 && a->w >= 16 && (a->h * a->w) % 256 == 0) || (a->h == 8 && a->w == 8)), ADM_E_ARG,
+                "adm_conv: fold0 needs a 3x3 conv with the GroupNorm + SiLU prologue, bf16 output, no residual, an 8x8 map or one >= 16x16");
+    ADM_REQUIRE(a->fc0 > 0 && a->fc0 % KC == 0 && a->fc1 >= 0 && a->fc1 % KC == 0 && (a->fold1 != nullptr) == (a->fc1 > 0), ADM_E_SHAPE,
+                "adm_conv: fold channels (%d | %d) must be multiples of 32", a->fc0, a->fc1);
+    ADM_REQUIRE(adm_aligned16(a->fold0) && adm_aligned16(a->fold1), ADM_E_ALIGN, "adm_conv: unaligned fold pointer");
+    k.f0 = a->fold0; k.f1 = a->fold1; k.FC0 = a->fc0; k.FC1 = a->fc1;
+    k.wbytes += (unsigned)(((long long)(a->fc0 + a->fc1) / KC) * k.ntiles16 * 1024);   // the 1x1 weights follow the 3x3 weights
+    prologue = 4;
+  }
   if (a->up_phase == 5) {   // four packed weights back to back
     ADM_REQUIRE((long long)k.wbytes * 4 < (1ll << 31), ADM_E_SHAPE, "adm_conv: up_phase 5: weights beyond 2 GiB");
     k.phase_bytes = k.wbytes;
@@ -1635,12 +1712,13 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     return adm_check_launch("adm_conv(split-K reduce)");
   }
   ADM_REQUIRE(a->out_mode == 0 || variant == 3, ADM_E_ARG, "adm_conv: fp32 NCHW output runs on tiling variant 3 (the 16-wide tile)");
+  ADM_REQUIRE(!a->fold0 || variant == 5 || variant == 6, ADM_E_ARG, "adm_conv: the skip-connection fold runs on tiling variants 5 / 6");
   switch (variant) {
     case 3: return dispatch_conv<4, 1, 4, 1, 2, true>(k, a->taps, a->prologue, s);  // 256 x 16 (output head / stem backward)
     // 8 waves, 192-wide tile: the prologue transform / halo staging is shared by twice as many MFMAs
-    case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, a->prologue, s);
+    case 5: return small_map ? dispatch_conv<2, 4, 4, 3, 2>(k, a->taps, prologue, s) : dispatch_conv<2, 4, 8, 3, 2>(k, a->taps, prologue, s);
     // 8 waves, 128-wide tile (channel counts that are multiples of 128 but not of 192: the classifier)
-    case 6: return small_map ? dispatch_conv<2, 4, 4, 2, 2>(k, a->taps, a->prologue, s) : dispatch_conv<2, 4, 8, 2, 2>(k, a->taps, a->prologue, s);
+    case 6: return small_map ? dispatch_conv<2, 4, 4, 2, 2>(k, a->taps, prologue, s) : dispatch_conv<2, 4, 8, 2, 2>(k, a->taps, prologue, s);
     default: ADM_FAIL(ADM_E_ARG, "adm_conv: unknown variant %d", variant);
   }
 }

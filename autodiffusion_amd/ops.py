@@ -300,7 +300,7 @@ def splitk_1x1_for(h: int, w: int, cin: int, cout: int) -> int:
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
          out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1,
-         w_up=None, gnb=None, geglu=False):
+         w_up=None, gnb=None, geglu=False, fold=None):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): 16-bit NHWC (bf16, or fp16 for an fp16-torso model: the library is picked by x0's dtype).  Returns the same
@@ -310,6 +310,8 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     (pack_conv_weight_up) an in_up conv runs as four phase launches of 2x2 live taps each (4/9 of the MACs).
     geglu: w_packed / bias are an interleaved (value, gate) projection (geglu_interleave); returns [n, h, w, cout // 2] =
     value * gelu(gate) -- the Stable-Diffusion GEGLU without the [.., cout] tensor (1x1 resident-tile kernel only).
+    fold=(xs0, xs1 | None): the ResBlock's skip_connection inside this (out_layers) conv: w_packed = fold_weights(3x3, 1x1), bias = the
+    sum of both biases; extra one-tap K-steps over the block input (xs0 | xs1) replace the 1x1 launch and the residual operand.
     """
     n, h, w, c0 = x0.shape
     if (in_up and w_up is not None and UPCONV_PHASES and taps == 9 and x1 is None and res is None and not res_up
@@ -351,6 +353,12 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     a.w_packed32 = _ptr(w_packed32, x0.dtype, "w_packed32")
     a.taps, a.out_mode, a.variant = taps, int(out_f32_nchw), variant
     a.in_up, a.res_up = int(in_up), int(res_up)
+    if fold is not None:
+        f0, f1 = fold
+        if tuple(f0.shape[:3]) != (n, h, w) or (f1 is not None and tuple(f1.shape[:3]) != (n, h, w)):
+            raise AdmError("conv(fold=...): the folded skip input must have the output's map")
+        a.fold0, a.fold1 = _ptr(f0, x0.dtype, "fold0"), _ptr(f1, x0.dtype, "fold1")
+        a.fc0, a.fc1 = f0.shape[3], 0 if f1 is None else f1.shape[3]
     ws = None
     if ksplit > 1:
         if out_f32_nchw or res_up:
@@ -361,7 +369,7 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
         w_packed32 = None  # the 32x32x16 kernel does not take the virtual upsample
     if variant == 0:
         variant = lib.adm_conv_pick_variant(C.byref(a))  # the library's own rule (incl. the resident-tile 1x1 kernel)
-        if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw and ksplit <= 1:
+        if variant == 5 and taps == 9 and w_packed32 is not None and h >= 16 and w >= 16 and not out_f32_nchw and ksplit <= 1 and fold is None:
             variant = 7  # 3x3 on >= 16x16 maps, Cout a multiple of 192: the 32x32x16 MFMA kernel
         a.variant = variant
     fused = None
@@ -628,6 +636,16 @@ def vec_gn_bwd(x, gamma, stats, dz):
     check(_lib.load().adm_vec_gn_bwd(_ptr(x, torch.float32, "x"), _ptr(gamma, torch.float32, "gamma"), _ptr(stats, torch.float32, "stats"),
                                      _ptr(dz, torch.float32, "dz"), _ptr(dx), n, c, _stream()), "adm_vec_gn_bwd")
     return dx
+
+
+def fold_ok(h: int, w: int) -> bool:
+    """Maps on which adm_conv takes fold0 (the 8-wave tiles: 8x8, or >= 16x16 in whole 256-pixel tiles)."""
+    return (h == 8 and w == 8) or (h >= 16 and w >= 16 and (h * w) % 256 == 0)
+
+
+def fold_weights(w3_packed, w1_packed):
+    """Packed weights of conv(fold=...): the skip_connection's 1x1 K-steps follow the 3x3 conv's (same Cout tiling)."""
+    return torch.cat([w3_packed.reshape(-1), w1_packed.reshape(-1)]).contiguous()
 
 
 def pack_conv_weight_bwd(w, dtype=BF16):

@@ -130,6 +130,9 @@ class UNetModel(HipModule):
                 if b.has_skip_conv:
                     d["ws"] = pack(P[f"{p}.skip_connection.weight"])
                     d["wsb"] = f32(f"{p}.skip_connection.bias")
+                    if self.fold_skip:
+                        d["w2f"] = ops.fold_weights(d["w2"], d["ws"])
+                        d["c2fb"] = (d["c2b"] + d["wsb"]).contiguous()
                 pr.blocks[p] = d
             elif isinstance(b, SDDownSpec):
                 pr.blocks[p] = dict(w=pack(P[f"{p}.op.weight"]), b=f32(f"{p}.op.bias"),
@@ -184,13 +187,16 @@ class UNetModel(HipModule):
                      ksplit=self._ks(x0, x0.shape[3] + (0 if x1 is None else x1.shape[3])))
         off = pr.emb_off[s.prefix]
         aff2 = ops.gn_affine(h, d["g2"], d["b2"], add=emb[:, off:off + s.cout])
+        ks2 = self._ks(h, h.shape[3])
         if s.has_skip_conv:
+            if "w2f" in d and ks2 == 1 and ops.fold_ok(h.shape[1], h.shape[2]):
+                # skip_connection(x) + h (openaimodel.py:262) as extra one-tap K-steps of the out_layers conv (adm_conv_args.fold0)
+                return ops.conv(h, d["w2f"], d["c2fb"], s.cout, 9, aff=aff2, silu=True, fold=(x0, x1), want_stats=True)
             res = ops.conv(x0, d["ws"], d["wsb"], s.cout, 1, x1=x1)
         else:
             assert x1 is None
             res = x0
-        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True,
-                        ksplit=self._ks(h, h.shape[3]))
+        return ops.conv(h, d["w2"], d["c2b"], s.cout, 9, aff=aff2, silu=True, res=res, want_stats=True, ksplit=ks2)
 
     def _transformer(self, pr, s: SDTransformerSpec, x, kvs, n_ctx):
         d = pr.blocks[s.prefix]
@@ -250,6 +256,7 @@ class UNetModel(HipModule):
     # ------------------------------------------------------------------ forward
     use_graph = False  # replay one captured hipGraph per input shape (set by .enable_graph())
 
+    fold_skip = os.environ.get("ADM_FOLD_SKIP", "1") != "0"   # ResBlock skip_connection inside the out_layers conv's K loop (read when the weights are packed)
     fuse_geglu = os.environ.get("ADM_SD_FUSE_GEGLU", "1") != "0"   # GEGLU in the C -> 8C projection's epilogue (per model, never by batch)
     small_batch_splitk = False  # split the K loop of the 8x8 / 16x16-level 3x3 convs (set by .enable_splitk())
     upconv_phases = ops.UPCONV_PHASES   # Upsample convs as four 2x2-tap phase convs (a per-model choice, never by batch)

@@ -197,6 +197,8 @@ class AdmNet(HipModule):
         if plan.dynamic:
             self.layer_num = plan.layer_num
 
+    # ResBlock skip_connection folded into the out_layers conv's K loop (adm_conv_args.fold0); read when the weights are packed
+    fold_skip = os.environ.get("ADM_FOLD_SKIP", "1") != "0"
     with_backward = False  # classifier: also pack the backward-data weight images
     grad_scale = 1.0       # classifier with an fp16 backward network: static power-of-two scale of d(logits) (classifier.py)
 
@@ -310,6 +312,9 @@ class AdmNet(HipModule):
                 if b.has_skip_conv:
                     d["ws"] = pack(P[f"{p}.skip_connection.weight"])
                     d["wsb"] = f32(f"{p}.skip_connection.bias")
+                    if self.fold_skip and not (b.up or b.down):   # skip_connection as extra K-steps of the out_layers conv (ops.conv(fold=))
+                        d["w2f"] = ops.fold_weights(d["w2"], d["ws"])
+                        d["c2fb"] = (d["c2b"] + d["wsb"]).contiguous()
                 elif b.up:   # up-ResBlock: the first conv reads a 2x upsample -> four 2x2-tap phase convs (ops.pack_conv_weight_up)
                     d["w1_up"] = ops.pack_conv_weight_up(P[f"{p}.in_layers.2.weight"], cd)
                 pr.blocks[p] = d
@@ -409,6 +414,9 @@ class AdmNet(HipModule):
         else:
             aff2 = ops.gn_affine(h, d["g2"], d["b2"], film=film[:, off:], film_stride=pr.film_total)
         if s.has_skip_conv:
+            if "w2f" in d and mode is None and ops.fold_ok(h.shape[1], h.shape[2]):
+                # `self.skip_connection(x) + h` (reference unet.py:256) inside the out_layers conv: no 1x1 launch, no residual operand
+                return ops.conv(h, d["w2f"], d["c2fb"], s.cout, 9, aff=aff2, silu=True, fold=(xs, xs1), want_stats=True)
             res = ops.conv(xs, d["ws"], d["wsb"], s.cout, 1, x1=xs1)
         else:
             res = xs

@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 7   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu;
-                               7: adm_gn_finalize_add gained stats, adm_gn_bwd_finalize gained add / add_stride; the classifier's other heads */
+#define ADM_ABI_VERSION 8   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu;
+                               7: adm_gn_finalize_add gained stats, adm_gn_bwd_finalize gained add / add_stride; the classifier's other heads;
+                               8: adm_conv_args gained fold0 / fold1 / fc0 / fc1 */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -186,6 +187,13 @@ typedef struct adm_conv_args {
                         m = reference row m, row 2m + 1 = gate m = reference row cout/2 + m), and `out` is [n][h][w][cout / 2] =
                         value * gelu(gate) (exact erf GELU on the fp32 accumulators): the [.., cout] tensor is never written.  1x1 on the
                         resident-tile kernel only: raw input, no res / out_stats, cout %% 16 == 0, cout > 192                      */
+  const adm_bf16* fold0;  /* non-NULL: the ResBlock's `skip_connection(x) + h` (unet.py:216-222, 256) inside this out_layers conv: after the
+                             nine-tap K loop, (fc0 + fc1) / 32 one-tap raw K-steps over the block's INPUT x = (fold0 | fold1) [n][h][w][fc]
+                             with the skip_connection's 1x1 weights, which follow the 3x3 weights in w_packed (adm_pack_conv_weight of
+                             each, concatenated); bias = conv bias + skip bias.  3x3, prologue 2, bf16 output, no res, map 8x8 or >= 16x16,
+                             variant 0 / 5 / 6.  The 1x1 launch, its output tensor and the residual read of these tiles disappear.   */
+  const adm_bf16* fold1;
+  int32_t fc0, fc1;
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

@@ -475,6 +475,57 @@ def _split_k_case(ops, taps, n, hw, c0, c1, cout, ks, pro, use_res):
     torch.testing.assert_close(b1, b2, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("n,hw,cin,cout,fc0,fc1", [
+    (2, 16, 64, 192, 96, 0),        # one skip source, 3 one-tap K-steps
+    (3, 16, 192, 192, 192, 384),    # decoder block: the skip path reads the concat (h | skip) = 18 K-steps, 3x the main path's 6 chunks
+    (1, 32, 64, 128, 32, 0),        # a single skip K-step (the ring's clamps), 128-wide tile, 4 tiles per image
+    (2, 16, 96, 384, 64, 32),       # two Cout blocks; an odd number of main chunks (the skip path starts in halo buffer 1)
+    (5, 8, 128, 192, 96, 160),      # 8x8 maps: 128-pixel tiles of two images, ragged last tile
+    (4, 8, 256, 256, 256, 0),       # 8x8, 128-wide tile
+])
+def test_conv_with_the_skip_connection_folded_in(ops, n, hw, cin, cout, fc0, fc1):
+    """adm_conv_args.fold0: out_layers conv3x3(SiLU(GN-affine(h))) + skip_connection conv1x1(x) + both biases in ONE K loop (reference
+    unet.py:216-222, 256) against fp32 torch and against the two-launch form (1x1 conv, then 3x3 conv with the residual operand)."""
+    fc = fc0 + fc1
+    h = bf(rnd((n, cin, hw, hw), 1))
+    xs = bf(rnd((n, fc, hw, hw), 2))
+    w3 = bf(rnd((cout, cin, 3, 3), 3, (cin * 9) ** -0.5))
+    w1 = bf(rnd((cout, fc, 1, 1), 4, fc ** -0.5))
+    b3, b1 = 0.1 * rnd((cout,), 5), 0.1 * rnd((cout,), 6)
+    a, sh = 1 + 0.1 * rnd((n, cin), 7), 0.1 * rnd((n, cin), 8)
+    act = bf(F.silu(a[:, :, None, None] * h + sh[:, :, None, None]))
+    ref = F.conv2d(act, w3, b3, padding=1) + F.conv2d(xs, w1, b1)
+    hd, xd = nhwc_dev(h), nhwc_dev(xs)
+    x0, x1 = (xd[..., :fc0].contiguous(), xd[..., fc0:].contiguous()) if fc1 else (xd, None)
+    w3p, w1p = ops.pack_conv_weight(w3.to(DEV)), ops.pack_conv_weight(w1.to(DEV))
+    aff = (a.to(DEV), sh.to(DEV))
+    got = ops.conv(hd, ops.fold_weights(w3p, w1p), (b3 + b1).to(DEV), cout, 9, aff=aff, silu=True, fold=(x0, x1), want_stats=True)
+    assert_close_bf16(nchw_cpu(got), ref, "skip fold")
+    res = ops.conv(x0, w1p, b1.to(DEV), cout, 1, x1=x1)
+    two = ops.conv(hd, w3p, b3.to(DEV), cout, 9, aff=aff, silu=True, res=res, want_stats=True)
+    d = (nchw_cpu(got) - nchw_cpu(two)).abs().max().item()
+    assert d <= 2e-2 * ref.abs().max().item(), d
+    # closer to fp32 than the two-launch form (which rounds the 1x1 result to 16 bits before the add)
+    e1 = ((nchw_cpu(got) - ref).norm() / ref.norm()).item()
+    e2 = ((nchw_cpu(two) - ref).norm() / ref.norm()).item()
+    print(f"skip fold rel {e1:.3e}, two launches {e2:.3e}")
+    assert e1 <= e2 * 1.05
+    assert torch.equal(ops.conv(hd, ops.fold_weights(w3p, w1p), (b3 + b1).to(DEV), cout, 9, aff=aff, silu=True, fold=(x0, x1)), got)
+    if n > 1:   # batch independence
+        g1 = ops.conv(hd[:1].contiguous(), ops.fold_weights(w3p, w1p), (b3 + b1).to(DEV), cout, 9, aff=(a[:1].to(DEV), sh[:1].to(DEV)), silu=True,
+                      fold=(x0[:1].contiguous(), None if x1 is None else x1[:1].contiguous()))
+        assert torch.equal(g1, got[:1])
+    gamma, beta = (1 + 0.2 * rnd((cout,), 9)).to(DEV), (0.1 * rnd((cout,), 10)).to(DEV)
+    a1, b1_ = ops.gn_affine(got, gamma, beta)       # fused output statistics
+    ops.USE_FUSED_STATS = False
+    try:
+        a2, b2_ = ops.gn_affine(got, gamma, beta)
+    finally:
+        ops.USE_FUSED_STATS = True
+    torch.testing.assert_close(a1, a2, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(b1_, b2_, rtol=2e-4, atol=2e-5)
+
+
 def test_up_phase_and_gn_backward_epilogue_reject_unsupported_shapes(ops):
     """The two late-round conv modes fail loudly (AdmError with the library's message) outside their domain; the callers
     (ops.conv / classifier backward) route such shapes to the general paths instead."""

@@ -56,6 +56,31 @@ def test_unet_up_resblock_paths_and_sequential_guidance(monkeypatch):
     assert torch.equal(s1, s2) and torch.equal(u1, u2)
 
 
+def test_resblocks_without_the_skip_connection_fold():
+    """ADM_FOLD_SKIP=0: skip_connection as its own 1x1 launch and the residual operand of the out_layers conv, instead of extra one-tap
+    K-steps of that conv (adm_conv_args.fold0) -- UNet and classifier (forward on the tape path; the backward network is the same)."""
+    g = golden("full_adm64")
+    x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))
+    model, _ = adm64()
+    assert model.fold_skip
+    fold = model(x, t, y)
+    assert any("w2f" in d for d in model._packed.blocks.values())
+    model.fold_skip, model._packed = False, None      # the switch is read when the weights are packed
+    two = model(x, t, y)
+    assert not any("w2f" in d for d in model._packed.blocks.values())
+    rf, r2 = rel(fold, g["out"]), rel(two, g["out"])
+    print(f"ADM-G-64 UNet vs the reference's fp32 output: skip fold {rf:.3e}, two launches {r2:.3e}")
+    assert rf < 2e-2 and r2 < 2e-2 and not torch.equal(fold, two) and rel(fold, two.cpu().numpy()) < 1.5e-2   # two bf16 evaluations, each ~1e-2 from fp32
+    gc = golden("full_clf64")
+    xc, tc, yc = (torch.from_numpy(gc[k]).to(DEV) for k in ("x", "t", "y"))
+    c64 = clf(64, 4)
+    gf = c64.log_prob_grad(xc, tc, yc, 1.0)
+    c64.fold_skip, c64._packed = False, None
+    g2 = c64.log_prob_grad(xc, tc, yc, 1.0)
+    print(f"guidance gradient vs the reference's autograd: skip fold {rel(gf, gc['grad']):.3e}, two launches {rel(g2, gc['grad']):.3e}")
+    assert rel(gf, gc["grad"]) < 5e-2 and rel(g2, gc["grad"]) < 5e-2 and not torch.equal(gf, g2)
+
+
 def test_classifier_gn_backward_as_three_passes():
     """ADM_FUSE_GN_BWD=0: partial -> finalize -> apply instead of the backward conv's fused epilogue."""
     gc = golden("full_clf64")
@@ -92,7 +117,7 @@ def test_fid_accumulation_without_the_side_stream(monkeypatch):
 
 
 def test_sd_unet_non_default_schedules(monkeypatch):
-    """ADM_SD_FUSE_GEGLU=0 (projection -> tensor -> adm_geglu), ADM_SD_STRIDE2=0 (Downsample as stride-1 conv + pixel pick),
+    """ADM_FOLD_SKIP=0, ADM_SD_FUSE_GEGLU=0 (projection -> tensor -> adm_geglu), ADM_SD_STRIDE2=0 (Downsample as stride-1 conv + pixel pick),
     ADM_SD_SPLITK (split-K on / off; ADM_SD_SPLITK_1X1=1: the wide 1x1 projections too), ADM_UPCONV_PHASES=0 on the reference-captured w320 fixture; ADM_SD_SPLIT_GUIDANCE=0 (one batch of
     2N instead of two half batches on two streams) bitwise equal through the DDIM sampler."""
     from autodiffusion_amd import sd_unet
@@ -104,7 +129,13 @@ def test_sd_unet_non_default_schedules(monkeypatch):
     m = _model(plan, P)
     base = m(x, t, ctx)
     check(base, g["out"], "sd w320 default")
-    assert m.fuse_geglu and sd_unet.STRIDE2_TAPS
+    assert m.fuse_geglu and sd_unet.STRIDE2_TAPS and m.fold_skip
+    m2 = _model(plan, P)
+    m2.fold_skip = False                                  # ADM_FOLD_SKIP=0 (read when the weights are packed)
+    nofold = m2(x, t, ctx)
+    check(nofold, g["out"], "sd w320, skip_connection as its own launch")
+    assert not torch.equal(nofold, base)
+    del m2
     m.fuse_geglu = False
     two = m(x, t, ctx)
     m.fuse_geglu = True
