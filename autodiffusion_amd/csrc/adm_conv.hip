@@ -41,6 +41,9 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+#ifndef ADM_CONV_FOLD_RING
+#define ADM_CONV_FOLD_RING 2   // skip-connection fold: activation chunks in flight in registers (2; 3 measured 1-5 % slower per tile: profiles/r03/conv_tile_timing_fold.log)
+#endif
 #ifndef ADM_CONV_RD
 #define ADM_CONV_RD 2    // 1x1: activation stages in flight (register ring)
 #endif
@@ -478,7 +481,8 @@ conv_kernel(const ConvK p) {
   // from) go out once the accumulators' registers are free.
   constexpr int WRING = T3 ? 3 : (KS == 1 ? 4 : 2 * KS);
   uint4 wr[WRING][TN];
-  uint4 ring[ADM_CONV_RD][PASSES];
+  constexpr int RINGN = FOLD ? ADM_CONV_FOLD_RING : ADM_CONV_RD;
+  uint4 ring[RINGN][PASSES];
   float4 bs[TN];
   // 1x1 loops: `last` = the tile's last chunk, ce - 1 (chunks - 1 unless the K loop is split: the split 1x1 tile runs chunks
   // [cb, ce) with cb even, so buffer parities (c & 1) and the first chunk in halo[0] agree)
@@ -691,29 +695,31 @@ conv_kernel(const ConvK p) {
         // the last nine-tap chunk stages skip chunk 0 (raw) into the other halo buffer and its taps 7, 8 fetch the skip path's
         // first two weight K-steps (they follow the 3x3 weights: ring slots 0, 1 again since 9 % 3 == 0)
         chunk(ce - 1, std::true_type{}, std::true_type{});
-        // ---- the skip_connection as one-tap K-steps: activations two chunks ahead in registers (ring of 2), weights two K-steps
-        // ahead (ring of 3), one barrier per step like the 1x1 loop; only the centre tap's fragment rows are read
+        // ---- the skip_connection as one-tap K-steps: activations RINGN chunks ahead in registers (chunk k >= 1 in slot k % RINGN),
+        // weights two K-steps ahead (ring of 3), one barrier per step like the 1x1 loop; only the centre tap's fragment rows are read
         const int fch = (p.FC0 + p.FC1) / KCS, flast = fch - 1;
         const int fstep0 = chunks * 9;
         const unsigned char* const hc = halo + (HW2 + 1) * ROWB;     // centre tap
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = fold_load(min(1, flast), ps);
+        for (int q = 1; q <= RINGN; ++q) {
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) ring[0][ps] = fold_load(min(2, flast), ps);
+          for (int ps = 0; ps < PASSES; ++ps) ring[q % RINGN][ps] = fold_load(min(q, flast), ps);
+        }
         auto fbody = [&](int j, auto s_) {
-          constexpr int S = decltype(s_)::value;     // j % 6: ring slots (j + 1) & 1 (activations), j % 3 (weights)
+          constexpr int S = decltype(s_)::value;     // j % 6: ring slots (j + 1) % RINGN (activations), j % 3 (weights)
           if (j > flast) return;
           const int buf = (ce + j) & 1;
           load_w(fstep0 + min(j + 2, flast), wr[(S + 2) % 3]);
           mfma_tap(hc + buf * Lds::HB, wr[S % 3]);
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) raw_write(ring[(S + 1) & 1][ps], ps, buf ^ 1);
+          for (int ps = 0; ps < PASSES; ++ps) raw_write(ring[(S + 1) % RINGN][ps], ps, buf ^ 1);
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) ring[(S + 1) & 1][ps] = fold_load(min(j + 3, flast), ps);
+          for (int ps = 0; ps < PASSES; ++ps) ring[(S + 1) % RINGN][ps] = fold_load(min(j + 1 + RINGN, flast), ps);
           __syncthreads();
         };
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
         using J3 = std::integral_constant<int, 3>; using J4 = std::integral_constant<int, 4>; using J5 = std::integral_constant<int, 5>;
+        static_assert(6 % RINGN == 0, "skip loop: unrolled by 6, ring slots are compile-time");
         for (int j0 = 0; j0 < fch; j0 += 6) {
           fbody(j0, J0{}); fbody(j0 + 1, J1{}); fbody(j0 + 2, J2{});
           fbody(j0 + 3, J3{}); fbody(j0 + 4, J4{}); fbody(j0 + 5, J5{});

@@ -23,6 +23,14 @@ SHAPES = [
     ("qkv 384->1152 @32 1x1", 256, 32, 384, 1152, 1, 1, False),
     ("proj 384->384 @32 1x1 res", 256, 32, 384, 384, 1, 0, True),
 ]
+# FOLD=1: the out_layers convs of ResBlocks with a skip_connection, with the 1x1 folded in (adm_conv_args.fold0) -- name, n, hw, cin, cout, skip channels
+FOLD_SHAPES = [
+    ("192->192 @64 + skip 576", 256, 64, 192, 192, 576),
+    ("192->192 @64 + skip 384", 256, 64, 192, 192, 384),
+    ("384->384 @32 + skip 768", 256, 32, 384, 384, 768),
+    ("384->384 @32 + skip 192", 256, 32, 384, 384, 192),
+    ("576->576 @16 + skip 1152", 256, 16, 576, 576, 1152),
+]
 
 
 def main():
@@ -30,7 +38,10 @@ def main():
     fn = lib.adm_conv_timing_read
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    for name, n, hw, cin, cout, taps, prologue, res in SHAPES:
+    shapes = SHAPES
+    if os.environ.get("FOLD"):
+        shapes = [(nm, n, hw, cin, cout, 9, 2, fc) for nm, n, hw, cin, cout, fc in FOLD_SHAPES]
+    for name, n, hw, cin, cout, taps, prologue, res in shapes:
         k = 3 if taps == 9 else 1
         DT = torch.float16 if os.environ.get("ADM_TIMING_F16") else torch.bfloat16   # with ADM_HIP_LIB_F16 = the f16 timing build
         x0 = torch.randn(n, hw, hw, cin, device=DEV).to(DT)
@@ -40,22 +51,31 @@ def main():
         aff = (1 + 0.1 * torch.randn(n, cin, device=DEV), 0.1 * torch.randn(n, cin, device=DEV)) if prologue else None
         r = torch.randn(n, hw, hw, cout, device=DEV).to(DT) if res else None
         out = torch.empty(n, hw, hw, cout, dtype=DT, device=DEV)
+        kwf = {}
+        if os.environ.get("FOLD"):   # `res` carries the skip path's channel count
+            fc, r = res, None
+            xs = torch.randn(n, hw, hw, fc, device=DEV).to(DT)
+            w1 = ops.pack_conv_weight(torch.randn(cout, fc, 1, 1, device=DEV) * fc ** -0.5, DT)
+            if os.environ["FOLD"] == "1":
+                wp, kwf = ops.fold_weights(wp, w1), dict(fold=(xs, None))
+            else:                    # FOLD=0: the same layer as two launches; the stamps are those of the 3x3 conv with the residual
+                r = ops.conv(xs, w1, b, cout, 1)
         try:
-            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT, **kwf)
         except _lib.AdmError as e:   # an explicit variant that does not take this shape (e.g. VARIANT=8: 3x3 on maps >= 16x16 only)
             print(f"{name:28s} skipped: {str(e).split(': ', 2)[-1][:90]}")
             continue
         for _ in range(2):
-            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT, **kwf)
         torch.cuda.synchronize()
         scratch = np.zeros((16384, 16), dtype=np.uint64)
         fn(scratch.ctypes.data, 16384)  # clears the device buffer
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         for _ in range(int(os.environ.get("PRE", "0"))):  # sustained load before the stamped launch
-            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+            ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT, **kwf)
         e0.record()
-        ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT)
+        ops.conv(x0, wp, b, cout, taps, aff=aff, silu=(prologue == 2), res=r, out=out, variant=VARIANT, **kwf)
         e1.record()
         torch.cuda.synchronize()
         buf = np.zeros((16384, 16), dtype=np.uint64)
