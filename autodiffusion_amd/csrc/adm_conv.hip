@@ -1684,7 +1684,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   }
   ADM_REQUIRE(!(k.in_up || k.res_up || a->up_phase) || variant == 5 || variant == 6 || (variant == 8 && !a->up_phase), ADM_E_ARG, "adm_conv: in_up / res_up / up_phase need tiling variant 5 or 6");
   if (variant == 7) {  // 32x32x16 MFMA kernel: 3x3, maps >= 16x16, 256-pixel x 192-channel tile
-    ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out");
+    ADM_REQUIRE(a->w_packed32 && a->taps == 9 && a->out_mode == 0 && !a->fold0, ADM_E_ARG, "adm_conv: variant 7 needs w_packed32, 3x3, bf16 out, no fold");
     ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1, ADM_E_SHAPE, "adm_conv: variant 7 needs maps >= 16x16");
     k.w = a->w_packed32;
     k.wbytes = (unsigned)(((long long)(a->c0 + a->c1) / KC) * 9 * ((a->cout + 31) / 32) * 2048);
@@ -1701,8 +1701,8 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     // structural experiment (explicit only): the 256-pixel x 192-channel tile on FOUR waves, one per SIMD, each 128 pixels x
     // 96 channels (8 x 6 MFMA tiles = 192 accumulator registers of a 512-register wave): half the LDS fragment reads and half
     // the weight-fragment loads per MFMA of the 8-wave tile, and registers to spare for the tile switch
-    ADM_REQUIRE(a->taps == 9 && !small_map && a->out_mode == 0 && k.ksplit <= 1 && !a->up_phase && a->prologue != 3, ADM_E_ARG,
-                "adm_conv: variant 8 takes 3x3 convs with bf16 output on maps >= 16x16");
+    ADM_REQUIRE(a->taps == 9 && !small_map && a->out_mode == 0 && k.ksplit <= 1 && !a->up_phase && a->prologue != 3 && !a->fold0, ADM_E_ARG,
+                "adm_conv: variant 8 takes 3x3 convs with bf16 output on maps >= 16x16 (no fold)");
     ADM_REQUIRE(conv_geometry(k, 256, 9, 324) && k.TI == 1 && k.TW == 16 && k.TH == 16, ADM_E_SHAPE, "adm_conv: variant 8 needs maps >= 16x16");
     return launch_conv<2, 2, 8, 6, 1, 9, 324, 1, false>(k, a->prologue, k.N * k.tiles_x * k.tiles_y, s);
   }

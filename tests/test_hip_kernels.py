@@ -534,6 +534,14 @@ def test_up_phase_and_gn_backward_epilogue_reject_unsupported_shapes(ops):
     w = torch.zeros(64, 64, 3, 3, device=DEV)
     b = torch.zeros(64, device=DEV)
     aff = (torch.ones(2, 64, device=DEV), torch.zeros(2, 64, device=DEV))
+    x16 = torch.zeros(2, 16, 16, 64, dtype=torch.bfloat16, device=DEV)
+    wf = ops.fold_weights(ops.pack_conv_weight(w), ops.pack_conv_weight(torch.zeros(64, 64, 1, 1, device=DEV)))
+    with pytest.raises(AdmError, match="fold"):     # the fold needs the GN + SiLU prologue, no residual, an 8-wave tile
+        ops.conv(x16, wf, b, 64, 9, fold=(x16, None))
+    with pytest.raises(AdmError, match="fold"):
+        ops.conv(x16, wf, b, 64, 9, aff=aff, silu=True, fold=(x16, None), variant=8)
+    with pytest.raises(AdmError, match="fold"):
+        ops.conv(x16[:, :4, :4].contiguous(), wf, b, 64, 9, aff=aff, silu=True, fold=(x16[:, :4, :4].contiguous(), None))
     with pytest.raises(AdmError, match="fused statistics|prologue 3"):
         ops.conv(x8, ops.pack_conv_weight(w), b, 64, 9, gnb=(x8, aff))          # 8x8 map: no 256-pixel tiles
     with pytest.raises(AdmError, match="gnb"):
