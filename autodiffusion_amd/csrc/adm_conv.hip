@@ -41,6 +41,9 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+#ifndef ADM_FOLD_ABL
+#define ADM_FOLD_ABL 0
+#endif
 #ifndef ADM_CONV_FOLD_RING
 #define ADM_CONV_FOLD_RING 2   // skip-connection fold: activation chunks in flight in registers (2; 3 measured 1-5 % slower per tile: profiles/r03/conv_tile_timing_fold.log)
 #endif
@@ -700,21 +703,58 @@ conv_kernel(const ConvK p) {
         const int fch = (p.FC0 + p.FC1) / KCS, flast = fch - 1;
         const int fstep0 = chunks * 9;
         const unsigned char* const hc = halo + (HW2 + 1) * ROWB;     // centre tap
+        // From skip chunk 1 on only the tile's BM CENTRE pixels are staged (into their slots of the halo geometry; the border slots
+        // keep stale data no centre-tap fragment row reads): the skip steps stream their operand at the HBM rate (ablation,
+        // profiles/r03/conv_fold_ablation.log: half a step is the wait for these loads, at 20.7 KB per step and CU = 5.3 TB/s over
+        // the chip), and the halo ring is 27 % of those bytes.  The per-lane addresses are made here, not in tile_setup: nothing
+        // may stay live across the nine-tap loop.
+        constexpr int CPASS = BM * SEGP / NT;
+        static_assert(CPASS * NT == BM * SEGP && CPASS <= PASSES, "centre staging: whole passes");
+        int cpix[CPASS], cslot[CPASS];
+        {
+          int tid_c = tid;
+          asm volatile("" : "+v"(tid_c));
+          const int nimg_c = min(p.TI, p.N - img0);
+#pragma unroll
+          for (int ps = 0; ps < CPASS; ++ps) {
+            const int pp = (tid_c + ps * NT) >> SEGSH;                     // centre pixel 0 .. BM - 1
+            const int ti = pp >> p.thw_shift, rem = pp & ((1 << p.thw_shift) - 1);
+            const int py = rem >> p.tw_shift, px = rem & (p.TW - 1);
+            cpix[ps] = ti < nimg_c ? (ti * p.H + y0 + py) * p.W + x0 + px : -1;
+            cslot[ps] = (ti * HPI + (py + 1) * HW2 + px + 1) * ROWB + (tid_c & (SEGP - 1)) * 16;
+          }
+        }
+        auto cload = [&](int k, int ps) -> uint4 {
+          const int f0chunks = p.FC0 / KCS;
+          const bool first = k < f0chunks;
+          const int cs = first ? p.FC0 : p.FC1, co = (first ? k : k - f0chunks) * KCS;
+          const __amdgpu_buffer_rsrc_t rs = first ? rs2 : rs3;
+          const unsigned voff = cpix[ps] >= 0 ? (unsigned)(cpix[ps] * cs + co + seg * 8) * 2u : OOB;
+          return bufload16(rs, voff, 0);
+        };
 #pragma unroll
         for (int q = 1; q <= RINGN; ++q) {
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) ring[q % RINGN][ps] = fold_load(min(q, flast), ps);
+          for (int ps = 0; ps < CPASS; ++ps) ring[q % RINGN][ps] = cload(min(q, flast), ps);
         }
         auto fbody = [&](int j, auto s_) {
           constexpr int S = decltype(s_)::value;     // j % 6: ring slots (j + 1) % RINGN (activations), j % 3 (weights)
           if (j > flast) return;
           const int buf = (ce + j) & 1;
+#if ADM_FOLD_ABL != 2   // diagnostic builds only (wrong results): 1 no activation loads, 2 no weight loads, 3 no LDS park, 4 no MFMAs
           load_w(fstep0 + min(j + 2, flast), wr[(S + 2) % 3]);
+#endif
+#if ADM_FOLD_ABL != 4
           mfma_tap(hc + buf * Lds::HB, wr[S % 3]);
+#endif
+#if ADM_FOLD_ABL != 3
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) raw_write(ring[(S + 1) % RINGN][ps], ps, buf ^ 1);
+          for (int ps = 0; ps < CPASS; ++ps) *reinterpret_cast<uint4*>(halo + (buf ^ 1) * Lds::HB + cslot[ps]) = ring[(S + 1) % RINGN][ps];
+#endif
+#if ADM_FOLD_ABL != 1
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) ring[(S + 1) % RINGN][ps] = fold_load(min(j + 1 + RINGN, flast), ps);
+          for (int ps = 0; ps < CPASS; ++ps) ring[(S + 1) % RINGN][ps] = cload(min(j + 1 + RINGN, flast), ps);
+#endif
           __syncthreads();
         };
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
