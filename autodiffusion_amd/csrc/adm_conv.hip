@@ -1736,7 +1736,12 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
     }
   }
   // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
-  const bool small_map = a->h * a->w <= 64;
+  // ... and so do deep 1x1 convs (K >= 1280; LSUN-256's 1024-channel qkv at batch 64 measured 0.5 % slower with them) on 16x16 maps without fused statistics: SD v1's 1280-wide projections at 6-latent half
+  // batches are 6 pixel tiles of 256 x 10 Cout blocks on 256 CUs with 40-160 K-steps each; 128-pixel tiles double the tiles and halve
+  // the bytes per K-step (SD bench 62.9 -> 63.4 latents/s same-box; by shape only -- and the result does not depend on the tile:
+  // every output is the same chain of MFMA accumulations)
+  static const bool no_small1x1 = getenv("ADM_CONV_NO_SMALL1X1") != nullptr;   // A/B switch for measurements
+  const bool small_map = a->h * a->w <= 64 || (!no_small1x1 && a->taps == 1 && a->h * a->w <= 256 && a->c0 + a->c1 >= 1280 && !a->out_stats && k.ksplit <= 1);
   if (variant == 8) {
     // structural experiment (explicit only): the 256-pixel x 192-channel tile on FOUR waves, one per SIMD, each 128 pixels x
     // 96 channels (8 x 6 MFMA tiles = 192 accumulator registers of a 512-register wave): half the LDS fragment reads and half

@@ -199,6 +199,8 @@ CONV_CASES = [
     (1, 16, 576, 0, 1728, 1, 1, False, False, 0),  # ... 16x16 qkv: K = 576 (64-pixel tiles by LDS size), ragged last Cout block
     (1, 16, 192, 0, 192, 1, 1, True, False, 10),  # ... narrow output: 2 x 4 wave layout, block epilogue (residual)
     (3, 16, 128, 64, 128, 1, 0, False, False, 10),  # ... narrow output, wave-private epilogue, concat, idle 4th column
+    (6, 16, 1280, 0, 1280, 1, 0, True, False, 0),   # SD v1's 1280-wide projections at 16x16: staged kernel (K too deep for the resident tile), 128-pixel tiles
+    (2, 16, 1024, 256, 320, 1, 1, False, False, 0),  # ... concat (K = 1280), affine prologue, ragged last Cout block
     (2, 16, 64, 0, 192, 9, 2, True, False, 7),    # 32x32x16 MFMA kernel
     (1, 32, 64, 32, 384, 9, 0, False, False, 7),  # ... raw prologue, virtual concat, two channel blocks
     (3, 64, 32, 0, 96, 9, 1, True, False, 7),     # ... Cout below one tile: padded columns

@@ -189,17 +189,32 @@ bi = 0.1 * torch.randn(96, generator=g)
 goti = ops.conv2d(xi.to(dev), ops.pack_conv2d_weight(wi.to(dev), None, torch.float16), bi.to(dev), 3, 3, 1, (1, 1), relu=True)
 refi = F.relu(F.conv2d(xi.float().permute(0, 3, 1, 2), wi.half().float(), bi, padding=1)).permute(0, 2, 3, 1)
 e2 = float((goti.float().cpu() - refi).norm() / refi.norm())
-print("ERR", e1, e2)
+# deep 1x1 conv on a 16x16 map (SD v1's 1280-wide projections): 128-pixel tiles by default, 256-pixel tiles with ADM_CONV_NO_SMALL1X1
+xs = torch.randn(3, 16, 16, 1280, generator=g).to(torch.bfloat16)
+ws = torch.randn(320, 1280, 1, 1, generator=g) * 1280 ** -0.5
+bs = 0.1 * torch.randn(320, generator=g)
+gots = ops.conv(xs.to(dev), ops.pack_conv_weight(ws.to(dev)), bs.to(dev), 320, 1)
+refs = F.conv2d(xs.float().permute(0, 3, 1, 2), ws.to(torch.bfloat16).float(), bs).permute(0, 2, 3, 1)
+e3 = float((gots.float().cpu() - refs).norm() / refs.norm())
+import hashlib
+print("ERR", e1, e2, e3, hashlib.sha1(gots.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
 """
 
 
-@pytest.mark.parametrize("var", ["ADM_CONV_NO_RESIDENT", "ADM_CG_NO_LDS", ""])
+_DIGESTS = {}
+
+
+@pytest.mark.parametrize("var", ["ADM_CONV_NO_RESIDENT", "ADM_CG_NO_LDS", "ADM_CONV_NO_SMALL1X1", ""])
 def test_library_level_switches_in_a_child_process(var):
     env = dict(os.environ)
     if var:
         env[var] = "1"
     r = subprocess.run([sys.executable, "-c", _CHILD % ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    e1, e2 = (float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("ERR")][0].split()[1:])
-    print(var or "(default)", "1x1 conv rel", e1, "conv2d rel", e2)
-    assert e1 < 4e-3 and e2 < 2e-3, (var, e1, e2)
+    fields = [ln for ln in r.stdout.splitlines() if ln.startswith("ERR")][0].split()[1:]
+    e1, e2, e3 = (float(v) for v in fields[:3])
+    print(var or "(default)", "1x1 conv rel", e1, "conv2d rel", e2, "deep 1x1 conv at 16x16 rel", e3)
+    assert e1 < 4e-3 and e2 < 2e-3 and e3 < 4e-3, (var, e1, e2, e3)
+    _DIGESTS[var] = fields[3]
+    if "ADM_CONV_NO_SMALL1X1" in _DIGESTS and "" in _DIGESTS:   # the tile size does not change a single bit of the result
+        assert _DIGESTS["ADM_CONV_NO_SMALL1X1"] == _DIGESTS[""]
