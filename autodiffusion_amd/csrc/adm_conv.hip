@@ -1558,14 +1558,28 @@ int pick_variant(const adm_conv_args* a) {
   return w192 <= w128 ? 5 : 6;
 }
 
-// slabs of the fused output statistics: one per 256-pixel tile on maps >= 16x16, one per image on 8x8
-// maps; 0 = not offered for this configuration
+// 16x16 maps on the 128-pixel tiles (the 8x8 maps' instantiations; a 16x16 map is two tiles of 8 rows): deep convs of small-batch
+// callers.  SD v1's 1280-wide projections at 6-latent half batches are 6 pixel tiles of 256 x 10 Cout blocks on 256 CUs with 40-160
+// K-steps each; 128-pixel tiles double the tiles and halve the bytes per K-step (SD bench 62.9 -> 63.4 latents/s same-box with the 1x1
+// convs).  By shape only (K >= 1280: LSUN-256's 1024-channel qkv at batch 64 measured 0.5 % slower with them) -- and the result does
+// not depend on the tile: every output element is the same chain of MFMA accumulations (held bitwise by
+// tests/test_hip_switches.py).  ADM_CONV_NO_SMALL1X1: A/B switch.  The 3x3 convs of that level were tried on these tiles in place of
+// their split-K schedule: 64.1 -> 61.9 latents/s, not kept.
+bool small_tiles_16(const adm_conv_args* a) {
+  static const bool no_small1x1 = getenv("ADM_CONV_NO_SMALL1X1") != nullptr;
+  if (a->h != 16 || a->w != 16 || a->cout <= 16 || a->ksplit > 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 5 && a->variant != 6)) return false;
+  return a->taps == 1 && !no_small1x1 && a->c0 + a->c1 >= 1280;
+}
+
+// slabs of the fused output statistics: one per 256-pixel tile on maps >= 16x16 (four per 16x16 image on the 128-pixel tiles: two
+// tiles x two 64-pixel groups), one per image on 8x8 maps; 0 = not offered for this configuration
 int stat_slabs_for(const adm_conv_args* a, int variant) {
   if (a->out_mode != 0 || variant == 7) return 0;
   const int hw = a->h * a->w;
   if (a->up_phase) return (a->h >= 16 && a->w >= 16 && hw % 256 == 0) ? hw / 256 * 4 : 0;   // one slab per (source tile, phase)
   if (hw <= 64) return hw == 64 ? 1 : 0;
   if (a->h < 16 || a->w < 16 || hw % 256 != 0) return 0;
+  if (small_tiles_16(a)) return 4;
   return hw / 256;
 }
 
@@ -1735,13 +1749,9 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
       default: return launch_conv32<2>(k, m_tiles, s);
     }
   }
-  // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU
-  // ... and so do deep 1x1 convs (K >= 1280; LSUN-256's 1024-channel qkv at batch 64 measured 0.5 % slower with them) on 16x16 maps without fused statistics: SD v1's 1280-wide projections at 6-latent half
-  // batches are 6 pixel tiles of 256 x 10 Cout blocks on 256 CUs with 40-160 K-steps each; 128-pixel tiles double the tiles and halve
-  // the bytes per K-step (SD bench 62.9 -> 63.4 latents/s same-box; by shape only -- and the result does not depend on the tile:
-  // every output is the same chain of MFMA accumulations)
-  static const bool no_small1x1 = getenv("ADM_CONV_NO_SMALL1X1") != nullptr;   // A/B switch for measurements
-  const bool small_map = a->h * a->w <= 64 || (!no_small1x1 && a->taps == 1 && a->h * a->w <= 256 && a->c0 + a->c1 >= 1280 && !a->out_stats && k.ksplit <= 1);
+  // 8x8 maps use 128-pixel tiles (2 images): halves the halo so that 2 blocks still fit per CU; so do the deep convs of
+  // small_tiles_16 on 16x16 maps
+  const bool small_map = a->h * a->w <= 64 || small_tiles_16(a);
   if (variant == 8) {
     // structural experiment (explicit only): the 256-pixel x 192-channel tile on FOUR waves, one per SIMD, each 128 pixels x
     // 96 channels (8 x 6 MFMA tiles = 192 accumulator registers of a 512-register wave): half the LDS fragment reads and half

@@ -376,7 +376,8 @@ def test_attention_softmax_is_stable_for_large_logits(ops):
 
 @pytest.mark.parametrize("n,hw,cin,cout,taps,variant", [(3, 16, 64, 192, 9, 0), (2, 32, 32, 96, 9, 0), (5, 8, 64, 192, 9, 0),
                                                          (2, 64, 32, 64, 1, 0), (2, 16, 32, 128, 9, 6), (3, 8, 64, 128, 1, 0),
-                                                         (2, 16, 64, 384, 1, 0), (3, 8, 128, 256, 1, 0), (2, 16, 64, 192, 1, 10)])  # resident-tile 1x1
+                                                         (2, 16, 64, 384, 1, 0), (3, 8, 128, 256, 1, 0), (2, 16, 64, 192, 1, 10),  # resident-tile 1x1
+                                                         (3, 16, 1280, 320, 1, 0)])   # deep 1x1 at 16x16: 128-pixel tiles, four slabs per image
 def test_conv_fused_output_statistics_feed_groupnorm(ops, n, hw, cin, cout, taps, variant):
     """The sums accumulated in the conv epilogue must give the same GroupNorm affine as a separate pass."""
     k = 3 if taps == 9 else 1
