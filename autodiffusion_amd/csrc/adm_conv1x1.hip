@@ -39,6 +39,7 @@ struct Conv1K {
   const uint16_t* in0; const uint16_t* in1; const uint16_t* w; const uint16_t* res;
   const float* bias; const float* aa; const float* ab; uint16_t* out; float* stats;
   int N, HW, C0, C1, Cout, ntiles16, stat_slabs, m_tiles, nblocks_n;
+  int csplit, nbper;   // small launches: the Cout blocks of a pixel tile are shared out over `csplit` consecutive tiles of the list, nbper each
   unsigned wbytes, rcp_seg;   // rcp_seg = ceil(2^32 / (K/8)): idx / (K/8) == umulhi(idx, rcp_seg)
 };
 
@@ -91,7 +92,11 @@ conv1x1r_kernel(const Conv1K p) {
   const int tstart = xcd * (p.m_tiles >> 3) + min(xcd, p.m_tiles & 7);
 
   for (int tl = blockIdx.x >> 3; tl < tcount; tl += gx) {
-    const int pb = (tstart + tl) * BM;           // first pixel of the tile in the flattened [N*H*W] order
+    const int tq = tstart + tl;
+    const int pt = p.csplit > 1 ? tq / p.csplit : tq;
+    const int nb0 = p.csplit > 1 ? (tq - pt * p.csplit) * p.nbper : 0;
+    const int nb1 = p.csplit > 1 ? min(p.nblocks_n, nb0 + p.nbper) : p.nblocks_n;
+    const int pb = pt * BM;                      // first pixel of the tile in the flattened [N*H*W] order
     const int img = pb / p.HW;
     __syncthreads();                             // the previous tile's readers of A / tab / stg are done
     // ---- affine table of this image, then the activation tile: fetched, transformed, parked -- once
@@ -147,7 +152,7 @@ conv1x1r_kernel(const Conv1K p) {
     __syncthreads();
 
     const unsigned char* const alane = A + (wm * TM * 16 + lc) * RB + lq * 16;  // fragment row of this lane in its first pixel tile
-    for (int nb = 0; nb < p.nblocks_n; ++nb) {
+    for (int nb = nb0; nb < nb1; ++nb) {
       // ---- K loop over the resident tile: no barrier, no global activation traffic
       unsigned wofs[TN];
       f32x4 acc[TM][TN];
@@ -465,6 +470,26 @@ int adm_conv1x1_resident_launch(const adm_conv_args* a, void* stream) {
   k.m_tiles = (int)((long long)a->n * k.HW / bm);
   const int bn = wm == 1 ? 384 : 192;
   k.nblocks_n = (a->cout + bn - 1) / bn;
+  // Few pixel tiles (small-batch callers: SD v1 at 6-latent half batches has 96 tiles at 32x32) and several Cout blocks per tile: the
+  // blocks of a tile are shared out over `csplit` neighbouring entries of the tile list (the same XCD: the second fetch of the
+  // activation tile is an L2 hit), so that the launch covers the CUs.  This depends on the batch -- and cannot change a result:
+  // every output element is computed by the same instructions on the same operands whichever block of the grid owns it.
+  k.csplit = 1;
+  {
+    static const bool no_csplit = getenv("ADM_C1_NO_CSPLIT") != nullptr;   // A/B switch for measurements
+    int ncu = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    if (!no_csplit && k.nblocks_n > 1 && k.m_tiles < ncu) {
+      int want = (ncu + k.m_tiles - 1) / k.m_tiles;
+      if (want > k.nblocks_n) want = k.nblocks_n;
+      if (want > 4) want = 4;
+      k.csplit = want;
+    }
+  }
+  k.nbper = (k.nblocks_n + k.csplit - 1) / k.csplit;
+  k.csplit = (k.nblocks_n + k.nbper - 1) / k.nbper;     // no empty parts
+  k.m_tiles *= k.csplit;
   const int kk = a->c0 + a->c1;
   k.wbytes = (unsigned)(((long long)kk / 32) * k.ntiles16 * 1024);
   const unsigned segk = (unsigned)kk / 8;

@@ -197,14 +197,23 @@ gots = ops.conv(xs.to(dev), ops.pack_conv_weight(ws.to(dev)), bs.to(dev), 320, 1
 refs = F.conv2d(xs.float().permute(0, 3, 1, 2), ws.to(torch.bfloat16).float(), bs).permute(0, 2, 3, 1)
 e3 = float((gots.float().cpu() - refs).norm() / refs.norm())
 import hashlib
-print("ERR", e1, e2, e3, hashlib.sha1(gots.cpu().view(torch.int16).numpy().tobytes()).hexdigest())
+# resident-tile 1x1 conv with few pixel tiles and several Cout blocks (+ residual, fused statistics): the blocks are shared out over
+# neighbouring grid entries by default, one entry per pixel tile with ADM_C1_NO_CSPLIT
+w3 = torch.randn(1152, 128, 1, 1, generator=g) * 128 ** -0.5
+b3 = 0.1 * torch.randn(1152, generator=g)
+r3 = torch.randn(2, 16, 16, 1152, generator=g).to(torch.bfloat16)
+got3 = ops.conv(x.to(dev), ops.pack_conv_weight(w3.to(dev)), b3.to(dev), 1152, 1, res=r3.to(dev), want_stats=True)
+ref3 = F.conv2d(x.float().permute(0, 3, 1, 2), w3.to(torch.bfloat16).float(), b3).permute(0, 2, 3, 1) + r3.float()
+e4 = float((got3.float().cpu() - ref3).norm() / ref3.norm())
+dg = lambda t: hashlib.sha1(t.cpu().contiguous().view(torch.int16).numpy().tobytes()).hexdigest()
+print("ERR", e1, e2, e3, dg(gots), e4, dg(got3), hashlib.sha1(got3._adm_stats[0].cpu().numpy().tobytes()).hexdigest())
 """
 
 
 _DIGESTS = {}
 
 
-@pytest.mark.parametrize("var", ["ADM_CONV_NO_RESIDENT", "ADM_CG_NO_LDS", "ADM_CONV_NO_SMALL1X1", ""])
+@pytest.mark.parametrize("var", ["ADM_CONV_NO_RESIDENT", "ADM_CG_NO_LDS", "ADM_CONV_NO_SMALL1X1", "ADM_C1_NO_CSPLIT", ""])
 def test_library_level_switches_in_a_child_process(var):
     env = dict(os.environ)
     if var:
@@ -215,6 +224,10 @@ def test_library_level_switches_in_a_child_process(var):
     e1, e2, e3 = (float(v) for v in fields[:3])
     print(var or "(default)", "1x1 conv rel", e1, "conv2d rel", e2, "deep 1x1 conv at 16x16 rel", e3)
     assert e1 < 4e-3 and e2 < 2e-3 and e3 < 4e-3, (var, e1, e2, e3)
-    _DIGESTS[var] = fields[3]
+    e4 = float(fields[4])
+    assert e4 < 4e-3, (var, e4)
+    _DIGESTS[var] = (fields[3], fields[5], fields[6])
     if "ADM_CONV_NO_SMALL1X1" in _DIGESTS and "" in _DIGESTS:   # the tile size does not change a single bit of the result
-        assert _DIGESTS["ADM_CONV_NO_SMALL1X1"] == _DIGESTS[""]
+        assert _DIGESTS["ADM_CONV_NO_SMALL1X1"][0] == _DIGESTS[""][0]
+    if "ADM_C1_NO_CSPLIT" in _DIGESTS and "" in _DIGESTS:       # nor does the way a tile's Cout blocks are dealt to the grid (output and statistics)
+        assert _DIGESTS["ADM_C1_NO_CSPLIT"][1:] == _DIGESTS[""][1:]
