@@ -1567,6 +1567,7 @@ int pick_variant(const adm_conv_args* a) {
 // their split-K schedule: 64.1 -> 61.9 latents/s, not kept.
 bool small_tiles_16(const adm_conv_args* a) {
   static const bool no_small1x1 = getenv("ADM_CONV_NO_SMALL1X1") != nullptr;
+  // (SD's 640-wide 3x3 convs at 32x32 -- 120 tiles of 256 pixels at 6 latents -- were tried on these tiles too: 65.2 -> 64.3 latents/s, not kept)
   if (a->h != 16 || a->w != 16 || a->cout <= 16 || a->ksplit > 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 5 && a->variant != 6)) return false;
   return a->taps == 1 && !no_small1x1 && a->c0 + a->c1 >= 1280;
 }
@@ -1579,7 +1580,7 @@ int stat_slabs_for(const adm_conv_args* a, int variant) {
   if (a->up_phase) return (a->h >= 16 && a->w >= 16 && hw % 256 == 0) ? hw / 256 * 4 : 0;   // one slab per (source tile, phase)
   if (hw <= 64) return hw == 64 ? 1 : 0;
   if (a->h < 16 || a->w < 16 || hw % 256 != 0) return 0;
-  if (small_tiles_16(a)) return 4;
+  if (small_tiles_16(a)) return hw / 64;   // 128-pixel tiles x two 64-pixel groups
   return hw / 256;
 }
 
