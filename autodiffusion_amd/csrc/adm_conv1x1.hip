@@ -477,9 +477,12 @@ int adm_conv1x1_resident_launch(const adm_conv_args* a, void* stream) {
   k.csplit = 1;
   {
     static const bool no_csplit = getenv("ADM_C1_NO_CSPLIT") != nullptr;   // A/B switch for measurements
-    int ncu = 256, dev = 0;
+    static int ncu_dev[64] = {};        // CUs per device, queried once
+    int dev = 0;
     (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    int& ncu_c = ncu_dev[dev & 63];
+    if (ncu_c == 0 && (hipDeviceGetAttribute(&ncu_c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu_c <= 0)) ncu_c = 256;
+    const int ncu = ncu_c;
     if (!no_csplit && k.nblocks_n > 1 && k.m_tiles < ncu) {
       int want = (ncu + k.m_tiles - 1) / k.m_tiles;
       if (want > k.nblocks_n) want = k.nblocks_n;
