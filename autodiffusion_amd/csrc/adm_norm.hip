@@ -125,7 +125,10 @@ gn_partial_kernel(const uint16_t* __restrict__ in0, int c0, const uint16_t* __re
   }
 }
 
-// grid (n). Combine slabs and the channels of each of the 32 groups in double, emit the affine.
+// grid (n, 4): a block takes 8 of the 32 groups, one half-wave (32 lanes) per group = 8 channel lanes x 4 slab lanes.  Combine slabs
+// and the channels of each group in double, emit the affine.  The launch is a chain of dependent-latency loads, not bandwidth
+// (a few hundred 8-byte partial sums per group): one wave-quarter per group with every slab of a channel walked by one lane took
+// 5-7 us per call -- 3.4 % of the SD step (61 calls per evaluation on each guidance stream's critical path), 1 % of the guided step.
 __global__ void __launch_bounds__(256)
 gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const float* __restrict__ part1, int c1, int slabs1,
                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -133,44 +136,43 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
                    float* __restrict__ aff_b, float* __restrict__ stats, int hw, float eps,
                    const float* __restrict__ add, int add_stride) {
   const int c = c0 + c1;
-  __shared__ float gmean[32], grstd[32];
+  __shared__ float gmean[8], grstd[8];
   const int img = blockIdx.x;
   const int cpg = c / 32;
-  // one wave-quarter per group: thread t handles group t/8, strided over (slab, channel-in-group)
-  const int grp = threadIdx.x / 8, sub = threadIdx.x % 8;
+  const int gl = threadIdx.x / 32, grp = blockIdx.y * 8 + gl, sub = threadIdx.x % 32;
+  const int cl = sub % 8, sl0 = sub / 8;     // channel lane, slab lane
   double s = 0.0, ss = 0.0;
-  for (int j = sub; j < cpg; j += 8) {  // channels of the group; each may live in either part of the concat
+  for (int j = cl; j < cpg; j += 8) {  // channels of the group; each may live in either part of the concat
     const int ch = grp * cpg + j;
     const bool first = ch < c0;
     const float* base = first ? part0 : part1;
-    const int cs = first ? c0 : c1, cl = first ? ch : ch - c0, slabs = first ? slabs0 : slabs1;
-    // the launch is a few hundred dependent-latency loads long, not bandwidth: 8-byte loads, four slabs in flight
+    const int cs = first ? c0 : c1, cl_ = first ? ch : ch - c0, slabs = first ? slabs0 : slabs1;
     double cs1 = 0.0, cs2 = 0.0;
-    const float2* p = reinterpret_cast<const float2*>(base + (((long long)img * slabs) * cs + cl) * 2);
-    int sl = 0;
-    for (; sl + 4 <= slabs; sl += 4) {
-      const float2 v0 = p[(long long)sl * cs], v1 = p[(long long)(sl + 1) * cs], v2 = p[(long long)(sl + 2) * cs],
-                   v3 = p[(long long)(sl + 3) * cs];
+    const float2* p = reinterpret_cast<const float2*>(base + (((long long)img * slabs) * cs + cl_) * 2);
+    int sl = sl0;
+    for (; sl + 12 < slabs; sl += 16) {   // four slabs of this lane in flight
+      const float2 v0 = p[(long long)sl * cs], v1 = p[(long long)(sl + 4) * cs], v2 = p[(long long)(sl + 8) * cs],
+                   v3 = p[(long long)(sl + 12) * cs];
       cs1 += (double)v0.x; cs2 += (double)v0.y;
       cs1 += (double)v1.x; cs2 += (double)v1.y;
       cs1 += (double)v2.x; cs2 += (double)v2.y;
       cs1 += (double)v3.x; cs2 += (double)v3.y;
     }
-    for (; sl < slabs; ++sl) {
+    for (; sl < slabs; sl += 4) {
       const float2 v = p[(long long)sl * cs];
       cs1 += (double)v.x;
       cs2 += (double)v.y;
     }
-    if (add) {  // statistics of x + e[img, ch] from those of x: sum += hw*e, sum of squares += 2*e*sum + hw*e^2
+    if (add) {  // statistics of x + e[img, ch] from those of x: sum += hw*e, sum of squares += 2*e*sum + hw*e^2 (linear in this lane's share)
       const double e = (double)add[(long long)img * add_stride + ch];
-      cs2 += 2.0 * e * cs1 + (double)hw * e * e;
-      cs1 += (double)hw * e;
+      cs2 += 2.0 * e * cs1;
+      if (sl0 == 0) { cs2 += (double)hw * e * e; cs1 += (double)hw * e; }
     }
     s += cs1;
     ss += cs2;
   }
 #pragma unroll
-  for (int off = 4; off >= 1; off >>= 1) {
+  for (int off = 16; off >= 1; off >>= 1) {
     s += __shfl_xor(s, off);
     ss += __shfl_xor(ss, off);
   }
@@ -179,16 +181,16 @@ gn_finalize_kernel(const float* __restrict__ part0, int c0, int slabs0, const fl
     const double mean = s / cnt;
     double var = ss / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
-    gmean[grp] = (float)mean;
-    grstd[grp] = (float)(1.0 / sqrt(var + (double)eps));
+    gmean[gl] = (float)mean;
+    grstd[gl] = (float)(1.0 / sqrt(var + (double)eps));
     if (stats) {  // kept for the backward-data pass (classifier guidance)
-      stats[((long long)img * 32 + grp) * 2 + 0] = gmean[grp];
-      stats[((long long)img * 32 + grp) * 2 + 1] = grstd[grp];
+      stats[((long long)img * 32 + grp) * 2 + 0] = gmean[gl];
+      stats[((long long)img * 32 + grp) * 2 + 1] = grstd[gl];
     }
   }
   __syncthreads();
-  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-    const int g = ch / cpg;
+  for (int q = threadIdx.x; q < 8 * cpg; q += blockDim.x) {   // the channels of this block's 8 groups
+    const int g = q / cpg, ch = blockIdx.y * 8 * cpg + q;
     float a = grstd[g] * gamma[ch];
     float b = beta[ch] - gmean[g] * a;
     if (add) b += a * add[(long long)img * add_stride + ch];  // y = a*(x + e) + b applied to the stored x
@@ -318,7 +320,7 @@ extern "C" int adm_gn_finalize(const float* partial, const float* gamma, const f
   ADM_REQUIRE(partial && gamma && beta && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize: null pointer");
   ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0, ADM_E_SHAPE, "adm_gn_finalize: bad shape");
   ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize: film_stride < 2*c");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
                      (const float*)nullptr, 0, 0, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps,
                      (const float*)nullptr, 0);
   return adm_check_launch("adm_gn_finalize");
@@ -329,7 +331,7 @@ extern "C" int adm_gn_finalize_add(const float* partial, const float* gamma, con
                                    void* stream) {
   ADM_REQUIRE(partial && gamma && beta && add && aff_a && aff_b, ADM_E_ARG, "adm_gn_finalize_add: null pointer");
   ADM_REQUIRE(n > 0 && c > 0 && c % 32 == 0 && hw > 0 && slabs > 0 && add_stride >= c, ADM_E_SHAPE, "adm_gn_finalize_add: bad shape");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, partial, c, slabs,
                      (const float*)nullptr, 0, 0, gamma, beta, (const float*)nullptr, 0, aff_a, aff_b, stats, hw, eps,
                      add, add_stride);
   return adm_check_launch("adm_gn_finalize_add");
@@ -344,7 +346,7 @@ extern "C" int adm_gn_finalize2(const float* partial0, int c0, int slabs0, const
   ADM_REQUIRE(n > 0 && c0 > 0 && c % 32 == 0 && hw > 0 && slabs0 > 0 && (c1 == 0 || slabs1 > 0), ADM_E_SHAPE,
               "adm_gn_finalize2: bad shape");
   ADM_REQUIRE(!film || film_stride >= 2 * c, ADM_E_ARG, "adm_gn_finalize2: film_stride < 2*c");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partial0, c0, slabs0, partial1, c1,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, partial0, c0, slabs0, partial1, c1,
                      slabs1, gamma, beta, film, film_stride, aff_a, aff_b, stats, hw, eps, (const float*)nullptr, 0);
   return adm_check_launch("adm_gn_finalize2");
 }
