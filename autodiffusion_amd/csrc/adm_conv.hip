@@ -44,6 +44,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #ifndef ADM_FOLD_ABL
 #define ADM_FOLD_ABL 0
 #endif
+#ifndef ADM_CONV_1X1_NOEXIT
+#define ADM_CONV_1X1_NOEXIT 1   // 1x1 loop of the 128-pixel tiles without early exits (0: the exits, for A/B builds)
+#endif
+#ifndef ADM_CONV_1X1_DEEP
+#define ADM_CONV_1X1_DEEP 4   // 1x1 loop of the 128-pixel tiles: 4 (or 8) activation chunks in flight (8: weight K-steps too); 0: two (A/B builds). Same box, SD: 63.7 (0) / 64.2 (4) / 64.0 (8) latents/s
+#endif
 #ifndef ADM_CONV_FOLD_RING
 #define ADM_CONV_FOLD_RING 2   // skip-connection fold: activation chunks in flight in registers (2; 3 measured 1-5 % slower per tile: profiles/r03/conv_tile_timing_fold.log)
 #endif
@@ -482,9 +488,13 @@ conv_kernel(const ConvK p) {
   // The narrow register loads (first weight fragments: 3x3 ring of 3 K-steps, two in flight; 1x1 ring of
   // 4, three in flight, plus the activation segments of chunk 1; the bias fragment the accumulators start
   // from) go out once the accumulators' registers are free.
-  constexpr int WRING = T3 ? 3 : (KS == 1 ? 4 : 2 * KS);
+  // 1x1 loop of the 128-pixel tiles (never split-K: chunk 0 first): DEEPN activation chunks and weight K-steps in flight instead of
+  // two / three -- a step of these tiles is 8-12 MFMAs per wave, so two steps of prefetch distance are far less than the load latency
+  constexpr int DEEPN = ADM_CONV_1X1_DEEP;    // 0: off, else 4 or 8
+  constexpr bool DEEP1 = DEEPN != 0 && TAPS == 1 && KS == 1 && TM == 4 && !COLD && ADM_CONV_RD == 2;
+  constexpr int WRING = (TAPS == 9 || TAPS == 4) ? 3 : (KS == 1 ? (DEEP1 && DEEPN == 8 ? 8 : 4) : 2 * KS);
   uint4 wr[WRING][TN];
-  constexpr int RINGN = FOLD ? ADM_CONV_FOLD_RING : ADM_CONV_RD;
+  constexpr int RINGN = FOLD ? ADM_CONV_FOLD_RING : (DEEP1 ? DEEPN : ADM_CONV_RD);
   uint4 ring[RINGN][PASSES];
   float4 bs[TN];
   // 1x1 loops: `last` = the tile's last chunk, ce - 1 (chunks - 1 unless the K loop is split: the split 1x1 tile runs chunks
@@ -496,15 +506,27 @@ conv_kernel(const ConvK p) {
       load_w(cb * 9 + 1, wr[1]);
     } else {
       if constexpr (KS == 1) {
+        constexpr bool NOEXIT1 = ADM_CONV_1X1_NOEXIT && TM == 4 && !COLD;   // see the 1x1 loop: K-steps past the last read zero weights
         load_w(cb, wr[0]);
-        load_w(min(cb + 1, last), wr[1]);
-        load_w(min(cb + 2, last), wr[2]);
+        load_w(NOEXIT1 ? cb + 1 : min(cb + 1, last), wr[1]);
+        load_w(NOEXIT1 ? cb + 2 : min(cb + 2, last), wr[2]);
+        if constexpr (WRING == 8) {
+#pragma unroll
+          for (int q = 3; q < 7; ++q) load_w(NOEXIT1 ? cb + q : min(cb + q, last), wr[q]);
+        }
       } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) load_w(ks, wr[ks]);  // stage 0's K-steps
       }
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(cb + 1, last), ps);
+      if constexpr (DEEP1) {
+#pragma unroll
+        for (int q = 2; q < RINGN; ++q) {
+#pragma unroll
+          for (int ps = 0; ps < PASSES; ++ps) ring[q][ps] = halo_load(min(cb + q, last), ps);
+        }
+      }
 #if ADM_CONV_RD == 3
 #pragma unroll
       for (int ps = 0; ps < PASSES; ++ps) ring[2][ps] = halo_load(min(2, last), ps);
@@ -801,22 +823,41 @@ conv_kernel(const ConvK p) {
       } else
 #endif
       if constexpr (KS == 1) {
+        // NOEXIT (the 128-pixel tiles, never split-K): whole groups of four steps without the early exit.  With it every step is a
+        // control-flow merge and hipcc's wait-count insertion drains the prefetch (vmcnt(0) in two of the four steps, vmcnt(5) in
+        // the others, where the rings allow 6-8 loads in flight): the load latency was exposed in every other step -- 0.85 us per
+        // step on SD v1's 1280-wide projections, whose 8 MFMAs per wave need 0.1.  Steps past the last one multiply the re-read
+        // last chunk by weight fragments the buffer descriptor returns as zeros (K-step index beyond wbytes): they add nothing.
+        // (The 256-pixel tiles keep the exit: their GN-prologue instantiation spills without it, see below.)
+        constexpr bool NOEXIT = ADM_CONV_1X1_NOEXIT && TM == 4 && !COLD;
         auto body = [&](int c, auto sa_, auto sw_) {
           constexpr int SA = decltype(sa_)::value, SW = decltype(sw_)::value;
-          if (c > last) return;
+          if constexpr (!NOEXIT) {
+            if (c > last) return;
+          }
           const int c2 = min(c + 2, last);
           affine_park(affine_load(c2, img0), c & 1);
+          // activation ring: chunk k lives in slot k % RINGN; chunk c's slot is free (parked during step c - 1)
+          (void)SA;
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) ring[SA][ps] = halo_load(c2, ps);
-          load_w(min(c + 3, last), wr[(SW + 3) % 4]);
-          mfma_tap(halo + (c & 1) * Lds::HB, wr[SW]);
+          for (int ps = 0; ps < PASSES; ++ps) ring[SW % RINGN][ps] = halo_load(min(c + RINGN, last), ps);
+          load_w(NOEXIT ? c + WRING - 1 : min(c + WRING - 1, last), wr[(SW + WRING - 1) % WRING]);
+          mfma_tap(halo + (c & 1) * Lds::HB, wr[SW % WRING]);
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[SA ^ 1][ps], ps, (c + 1) & 1);
+          for (int ps = 0; ps < PASSES; ++ps) halo_write(ring[(SW + 1) % RINGN][ps], ps, (c + 1) & 1);
           __syncthreads();
         };
         // (Peeling the tail so that the unrolled group has no early exit removes the s_waitcnt vmcnt(0) hipcc puts
         // at the loop header, but the 192-wide GN-prologue instantiation then spills inside the loop: 530 -> 690 us
         // on qkv 384->1152 @32^2; the 128-wide tile, which does not spill, gained 3 %.)
+        if constexpr (WRING == 8) {
+          using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+          using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+          for (int c0 = cb; c0 < ce; c0 += 8) {
+            body(c0, I0{}, I0{}); body(c0 + 1, I1{}, I1{}); body(c0 + 2, I0{}, I2{}); body(c0 + 3, I1{}, I3{});
+            body(c0 + 4, I0{}, I4{}); body(c0 + 5, I1{}, I5{}); body(c0 + 6, I0{}, I6{}); body(c0 + 7, I1{}, I7{});
+          }
+        } else
         for (int c0 = cb; c0 < ce; c0 += 4) {   // cb: 0, or even (split-K)
           body(c0, I0{}, I0{});
           body(c0 + 1, I1{}, I1{});
