@@ -381,12 +381,13 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
             out._adm_stats = fused
         elif gnb is not None:
             raise AdmError("conv(gnb=...): the map does not offer fused statistics (needs >= 16x16, pixels % 256 == 0)")
-    if CONV_PROFILE is not None and (CONV_PROFILE_KEY is None or CONV_PROFILE_KEY == (variant, taps, h * w > 64, a.prologue)):
+    pkey = (variant, taps, h * w > 64, 4 if fold is not None else a.prologue)   # prologue 4: the folded launches are another kernel symbol (PROX = 4)
+    if CONV_PROFILE is not None and (CONV_PROFILE_KEY is None or CONV_PROFILE_KEY == pkey):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
         e1.record()
-        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * (c0 + c1) * taps, (variant, taps, h * w > 64, a.prologue),
+        CONV_PROFILE.append((e0, e1, 2.0 * n * h * w * cout * ((c0 + c1) * taps + a.fc0 + a.fc1), pkey,
                              (n, h, w, c0 + c1, cout)))
         return out
     check(lib.adm_conv(C.byref(a), _stream()), "adm_conv")
