@@ -19,6 +19,34 @@ from .schedule import apply_candidate
 
 NUM_CLASSES = 1000
 
+# Images evaluated per pass over the networks when several of the reference's (memory-driven) batches are merged: the cap scales
+# with the image area -- 256 images at 64x64 (the headline batch), 128 at 128x128, 64 at 256x256 -- so the activation working set of
+# a pass stays near the headline's whatever the model (a 128x128 ADM-G pass of 256 images would carry 4 x the headline's tape).
+PASS_IMAGES = {64: 256, 128: 128, 256: 64}
+
+
+def pass_cap(image_size: int) -> int:
+    for size in sorted(PASS_IMAGES):
+        if image_size <= size:
+            return PASS_IMAGES[size]
+    return max(1, PASS_IMAGES[256] * 256 * 256 // (image_size * image_size))
+
+
+def merge_policy(image_size: int, batch_size: int, requested: int = 0, rounds: int = None):
+    """-> (reference batches per pass, images per pass).  requested > 0 is taken as given (--merge_batches K); 0 = auto:
+    pass_cap(image_size) // batch_size, at least 1, at most the `rounds` a rank still has to run."""
+    merge = int(requested) if requested and requested > 0 else max(1, pass_cap(image_size) // max(1, batch_size))
+    if rounds is not None:
+        merge = max(1, min(merge, rounds))
+    return merge, merge * batch_size
+
+
+def graph_auto(image_size: int, images_per_pass: int) -> bool:
+    """`--use_graph auto`: hipGraph replay when the pass that is actually launched (the MERGED batch, which is what gets captured)
+    is small enough for the host's launch rate to be the floor: up to 256 64x64-equivalents per pass (measured: batch 100 x 2
+    at 64x64 replayed 6.78 s per candidate against 7.61 s eager; above that the GPU is the slower side)."""
+    return images_per_pass * (image_size / 64.0) ** 2 <= 256
+
 
 class CandidateEvaluator:
     def __init__(self, model, base_diffusion, classifier=None, *, image_size: int, use_ddim: bool = True,

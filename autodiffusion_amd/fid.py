@@ -91,6 +91,7 @@ class ActivationAccumulator:
         self.s2 = torch.zeros(dim, dim, dtype=torch.float64, device=self.device)
         self._side = None       # stream of add_from()
         self._pending = False
+        self.last_collective = None   # what pooled() last ran over the process group (bench.py / tests report it)
 
     OVERLAP = os.environ.get("ADM_FID_OVERLAP", "1") != "0"
 
@@ -145,8 +146,9 @@ class ActivationAccumulator:
         [n | s1 (dim) | s2 (dim^2)] (8 B + 16 KiB + 32 MiB per rank at dim 2048), summed in rank order (deterministic).
         n rides in the buffer (exact in float64), so no per-rank host synchronisation is needed."""
         import torch.distributed as dist
+        from .dist_util import collectives_on
         self.join()
-        if local or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if local or not collectives_on(group):
             return self.n, self.s1, self.s2
         world = dist.get_world_size(group)
         d = self.dim
@@ -159,6 +161,8 @@ class ActivationAccumulator:
         mine = mine.to(comm_dev)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine, group=group)
+        self.last_collective = {"op": "all_gather", "backend": dist.get_backend(group), "world_size": world,
+                                "bytes_per_rank": int(mine.numel() * 8), "device": str(mine.device)}
         tot = parts[0].to(self.device)
         for r in range(1, world):
             tot = tot + parts[r].to(self.device)

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import dist_util, logger
-from .evaluate import CandidateEvaluator
+from .evaluate import CandidateEvaluator, merge_policy
 from .fid import ActivationAccumulator, FIDStatistics, cal_fid
 from .schedule import space_timesteps
 
@@ -85,6 +85,7 @@ class EvolutionSearcher(object):
         # FID local to one GPU) and the FIDs are all-gathered back in order.
         self.population_parallel = population_parallel
         self._pending = []
+        self.last_flush = None
         self._ev = None
         if model is not None:
             self._ev = CandidateEvaluator(
@@ -121,8 +122,11 @@ class EvolutionSearcher(object):
         # rounds still to run (this rank takes one batch per round), and how many of them ride in one pass over the networks:
         # images are bitwise those of separate passes (CandidateEvaluator.sample_batches), the chip is filled like the headline batch
         rounds = -(-args.num_samples // (args.batch_size * world))
-        cap = 64 if int(getattr(args, "image_size", 64)) >= 256 else 256     # images per pass: the batches the bench lines are quoted at
-        merge = int(getattr(args, "merge_batches", 0) or max(1, cap // max(1, args.batch_size)))
+        merge, per_pass = merge_policy(int(getattr(args, "image_size", 64)), args.batch_size, int(getattr(args, "merge_batches", 0) or 0), rounds)
+        if merge > 1 and not getattr(self, "_merge_logged", False):   # once per search: log.txt shows the deviation from the reference's launch unit
+            logger.log(f"evaluating {merge} batches of {args.batch_size} per pass over the networks ({per_pass} images per pass; "
+                       "bitwise the images of separate passes; --merge_batches 1 restores the reference's launch unit)")
+            self._merge_logged = True
         while produced < args.num_samples:
             k = min(merge, rounds - batch_idx)
             seeds = [seed0 + 7919 * ((batch_idx + j) * world + rank) for j in range(k)]
@@ -139,7 +143,7 @@ class EvolutionSearcher(object):
                 produced += args.batch_size * world
                 batch_idx += 1
                 logger.log('created ' + str(min(produced, batch_idx * args.batch_size * world)) + ' samples')
-        if world > 1:
+        if world > 1 or (not local and dist_util.collectives_on()):
             import torch.distributed as dist
             dist.barrier()
         logger.log("sampling complete")
@@ -157,6 +161,11 @@ class EvolutionSearcher(object):
             arr = np.concatenate(host_images, axis=0)[: args.num_samples]
             fid = float(cal_fid(arr, 64, self.evaluator, ref_stats=self.ref_stats))
         fid_time = time.time() - t1
+        if acc is not None and acc.last_collective and not getattr(self, "_coll_logged", False):   # once per search
+            c = acc.last_collective
+            logger.log(f"collective: all_gather of the pooled FID statistics, backend {c['backend']}, {c['world_size']} rank(s), "
+                       f"{c['bytes_per_rank']} B per rank, on {c['device']}")
+            self._coll_logged = True
         logger.log('reset_time: ' + str(reset_time) + ', sample_time: ' + str(sample_time) + ', fid_time: ' + str(fid_time))
         self.last_times = {"reset_time": reset_time, "sample_time": sample_time, "fid_time": fid_time,
                            "images": int(args.num_samples), "batches_this_rank": batch_idx}
@@ -220,23 +229,34 @@ class EvolutionSearcher(object):
         if not self._pending:
             return
         import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        multi = dist_util.collectives_on()   # > 1 rank (or a forced world-size-1 group: the same calls through RCCL on one GPU)
         world = dist.get_world_size() if multi else 1
         rank = dist.get_rank() if multi else 0
         pending, self._pending = self._pending, []
         cands = [eval(c) for c in pending]
-        owner = self.assign_candidates([self.candidate_cost(c) for c in cands], world)
+        costs = [self.candidate_cost(c) for c in cands]
+        owner = self.assign_candidates(costs, world)
         fids = np.zeros(len(pending), dtype=np.float64)
+        t0 = time.time()
         for i, c in enumerate(cands):
             if owner[i] == rank:
                 fids[i] = self.get_cand_fid(args=self.args, cand=c)
+        mine_s = time.time() - t0
+        coll = None
         if multi:
             dev = self._ev.device if (self._ev is not None and dist.get_backend() == "nccl") else torch.device("cpu")
             mine = torch.from_numpy(fids).to(dev)
             parts = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine)
+            coll = {"op": "all_gather", "backend": dist.get_backend(), "world_size": world, "bytes_per_rank": int(mine.numel() * 8),
+                    "device": str(mine.device)}
             for i in range(len(pending)):
                 fids[i] = float(parts[owner[i]][i])
+            logger.log(f"collective: all_gather of {len(pending)} candidate FIDs, backend {coll['backend']}, {world} rank(s), on {coll['device']}")
+        # what this epoch's evaluation looked like from this rank (bench.py --workload population reports it per rank)
+        self.last_flush = {"candidates": len(pending), "owner": owner, "costs": costs,
+                           "assigned": sum(1 for o in owner if o == rank), "assigned_cost": sum(c for c, o in zip(costs, owner) if o == rank),
+                           "evaluate_s": mine_s, "collective": coll}
         for cand, fid in zip(pending, fids):
             self.vis_dict[cand]['fid'] = float(fid)
             logger.log('cand: {}, fid: {}'.format(cand, float(fid)) + self.fid_note)

@@ -216,28 +216,55 @@ class AdmNet(HipModule):
 
     use_graph = False
     GRAPH_CACHE = 12        # graphs kept per model (LRU); plan_graphs() raises it to the active candidate's needs
-    GRAPH_CACHE_MAX = 32    # ... up to this many (each graph owns a private activation pool)
-    _graph_eager = False    # the active candidate needs more graphs than GRAPH_CACHE_MAX: evaluate eagerly
+    GRAPH_CACHE_MAX = 32    # ... up to this many
+    # ... and never more than this fraction of the device's HBM in graph pools: every graph owns a PRIVATE activation pool
+    # (LSUN-256 at batch 64: one first-level activation is 2.1 GB, a forward's pool > 10 GB; a 13-32-step layer-skip candidate brings
+    # one launch sequence per distinct skip set).  Pools are measured at capture (reserved-memory delta).
+    GRAPH_POOL_FRACTION = float(os.environ.get("ADM_GRAPH_POOL_FRACTION", "0.45"))
+    _graph_eager = False    # the active candidate needs more graphs than fit (count or bytes): evaluate eagerly
+    _planned_sets = 1
+    _pool_bytes_seen = 0    # largest pool a capture of this model has needed so far
 
     def enable_graph(self, flag: bool = True):
         self.use_graph = bool(flag)
         return self
 
+    def _graph_budget(self) -> int:
+        dev = self.device
+        if dev.type != "cuda":
+            return 0
+        return int(self.GRAPH_POOL_FRACTION * torch.cuda.get_device_properties(dev).total_memory)
+
     def plan_graphs(self, distinct_sets: int):
         """Called per candidate (CandidateEvaluator.set_candidate) with the number of DISTINCT layer-skip sets its steps use:
         each needs its own captured launch sequence.  An LRU smaller than that count would miss on every evaluation of every
         batch (recapture = 2 warm-up runs + capture + sync: several times slower than eager), so the cache grows to the
-        candidate's needs up to GRAPH_CACHE_MAX; beyond that the candidate is evaluated eagerly, with one log line."""
+        candidate's needs up to GRAPH_CACHE_MAX graphs AND GRAPH_POOL_FRACTION of HBM in pools (the pool size of this model's
+        captures is known after the first one; _graphed re-checks at every capture); beyond either bound the candidate is
+        evaluated eagerly, with one log line."""
         from . import logger
-        if distinct_sets <= self.GRAPH_CACHE_MAX:
-            self.GRAPH_CACHE = max(type(self).GRAPH_CACHE, int(distinct_sets))
+        distinct_sets = max(1, int(distinct_sets))
+        self._planned_sets = distinct_sets
+        too_many = distinct_sets > self.GRAPH_CACHE_MAX
+        too_big = self._pool_bytes_seen > 0 and distinct_sets * self._pool_bytes_seen > self._graph_budget()
+        if not (too_many or too_big):
+            self.GRAPH_CACHE = max(type(self).GRAPH_CACHE, distinct_sets)
             self._graph_eager = False
         else:
-            if not self._graph_eager:
-                logger.log(f"hipGraph replay off for this candidate: {distinct_sets} distinct layer-skip sets > "
-                           f"{self.GRAPH_CACHE_MAX} cached graphs (eager launches instead of recapturing every step)")
+            if not self._graph_eager and self.use_graph:
+                why = (f"{distinct_sets} distinct layer-skip sets > {self.GRAPH_CACHE_MAX} cached graphs" if too_many else
+                       f"{distinct_sets} graphs x {self._pool_bytes_seen / 1e9:.1f} GB of private pool > {self._graph_budget() / 1e9:.0f} GB budget")
+                logger.log(f"hipGraph replay off for this candidate: {why} (eager launches instead of recapturing every step)")
             self._graph_eager = True
         return self
+
+    def graph_report(self):
+        """What the replay path holds: bench.py puts it on the JSON line of a --graph run."""
+        graphs = getattr(self._packed, "graphs", None) if getattr(self, "_packed", None) is not None else None
+        nb = [e[3] for e in graphs.values()] if graphs else []
+        return {"cached_graphs": len(nb), "pool_gb_total": round(sum(nb) / 1e9, 2), "pool_gb_largest": round(max(nb) / 1e9, 2) if nb else 0.0,
+                "budget_gb": round(self._graph_budget() / 1e9, 1), "planned_distinct_sets": self._planned_sets,
+                "eager_fallback": bool(self._graph_eager)}
 
     def _graphed(self, key, fn, inputs):
         """Replay (capturing at first use) fn(*inputs) -> tensor or tuple of tensors; inputs are device tensors."""
@@ -257,15 +284,28 @@ class AdmNet(HipModule):
                 for _ in range(2):
                     fn(*static_in)
             cur.wait_stream(side)
+            reserved0 = torch.cuda.memory_reserved(dev)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = fn(*static_in)
-            entry = graphs[key] = (graph, static_in, out)
-            while len(graphs) > self.GRAPH_CACHE:
+            pool = max(0, torch.cuda.memory_reserved(dev) - reserved0)   # the capture's private pool: fresh segments, never shared
+            self._pool_bytes_seen = max(self._pool_bytes_seen, pool)
+            entry = graphs[key] = (graph, static_in, out, pool)
+            budget = self._graph_budget()
+            while len(graphs) > 1 and (len(graphs) > self.GRAPH_CACHE or sum(e[3] for e in graphs.values()) > budget):
                 graphs.popitem(last=False)
+            if self._planned_sets * pool > budget:
+                # this candidate's launch sequences do not fit together: replay this one, then go eager (plan_graphs logs why)
+                for s_, t in zip(static_in, inputs):
+                    s_.copy_(t)
+                graph.replay()
+                res = tuple(o.clone() for o in out) if isinstance(out, tuple) else out.clone()
+                graphs.pop(key, None)
+                self.plan_graphs(self._planned_sets)
+                return res
         else:
             graphs.move_to_end(key)
-        graph, static_in, out = entry
+        graph, static_in, out = entry[:3]
         for s_, t in zip(static_in, inputs):
             s_.copy_(t)
         graph.replay()

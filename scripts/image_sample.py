@@ -22,7 +22,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from autodiffusion_amd import dist_util, logger  # noqa: E402
-from autodiffusion_amd.evaluate import CandidateEvaluator  # noqa: E402
+from autodiffusion_amd.evaluate import CandidateEvaluator, merge_policy  # noqa: E402
 from autodiffusion_amd.script_util import (add_dict_to_argparser, args_to_dict, create_model_and_diffusion,  # noqa: E402
                                            model_and_diffusion_defaults)
 
@@ -67,11 +67,12 @@ def main(argv=None):
     all_images, all_labels = [], []
     batch_idx = 0
     t1 = time.time()
-    # --merge_batches K (0 = auto: 256 // batch_size at 64x64 / 128x128, 64 // batch_size at 256x256): K of the reference's batches per
+    # --merge_batches K (0 = auto: evaluate.merge_policy): K of the reference's batches per
     # pass over the network, bitwise the same images (scripts/classifier_sample.py)
-    cap = 64 if args.image_size >= 256 else 256
-    merge = int(getattr(args, "merge_batches", 0) or max(1, cap // max(1, args.batch_size)))
     rounds = -(-args.num_samples // (args.batch_size * world))
+    merge, per_pass = merge_policy(args.image_size, args.batch_size, int(getattr(args, "merge_batches", 0) or 0), rounds)
+    if merge > 1:
+        logger.log(f"evaluating {merge} batches of {args.batch_size} per pass ({per_pass} images per pass; bitwise the images of separate passes)")
     while len(all_images) * args.batch_size < args.num_samples:
         k = max(1, min(merge, rounds - batch_idx))
         seeds = [args.seed * 1000003 + (batch_idx + j) * world + rank for j in range(k)]

@@ -12,9 +12,9 @@ not in this image).  With neither ``--features`` nor ``--inception_path`` the CL
 random-weight features is meaningless; ``--inception_random True`` opts in for throughput runs and tests, and every FID line
 of log.txt is then tagged "FID on RANDOM Inception weights".  ``--features pkg.module:factory``
 swaps in any callable ``factory(device) -> (features, dim)`` with ``features(uint8 NHWC device batch) -> fp32 [B, dim]``.
-``--ref_path`` is an .npz with ``mu``, ``sigma`` (written from the reference's pickled FIDStatistics).  ``--merge_batches`` (default 0 = auto: 256 // batch_size) evaluates that many reference batches per pass over the networks -- bitwise the
+``--ref_path`` is an .npz with ``mu``, ``sigma`` (written from the reference's pickled FIDStatistics).  ``--merge_batches`` (default 0 = auto: evaluate.merge_policy, 256 images per pass at 64x64, 128 at 128x128, 64 at 256x256) evaluates that many reference batches per pass over the networks -- bitwise the
 same images (every sub-batch draws from its own generator, and an image's result does not depend on the batch it rides in), with the chip
-filled like the headline batch.  ``--use_graph`` (default ``auto`` = on when ``--batch_size`` <= 128, e.g. the reference's 100) replays each UNet evaluation /
+filled like the headline batch.  ``--use_graph`` (default ``auto`` = on when the merged pass is at most 256 64x64-equivalents, e.g. the reference's batch 100 x 2) replays each UNet evaluation /
 guidance gradient as a captured hipGraph: bit-identical, and at such batches the eager path is bound by the host's launch rate
 (one whole candidate at batch 100: 7.29 s instead of 7.61 s, bench.py --workload candidate).  ``--population_parallel True`` shards whole
 candidates over ranks; otherwise every candidate's images are sharded and the statistics pooled.
@@ -75,7 +75,10 @@ def build_search_space(args, diffusion):
 def main(argv=None):
     args = create_argparser().parse_args(argv)
     from autodiffusion_amd.script_util import str2bool
-    args.use_graph = args.batch_size <= 128 if str(args.use_graph).lower() == "auto" else str2bool(args.use_graph)
+    from autodiffusion_amd.evaluate import graph_auto, merge_policy
+    # `auto` is decided on the MERGED batch -- the pass that is launched is what a graph captures
+    per_pass = merge_policy(args.image_size, args.batch_size, args.merge_batches, -(-args.num_samples // args.batch_size))[1]
+    args.use_graph = graph_auto(args.image_size, per_pass) if str(args.use_graph).lower() == "auto" else str2bool(args.use_graph)
     os.environ.setdefault("MASTER_PORT", args.MASTER_PORT)
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)

@@ -14,6 +14,8 @@ state-dict names.  Only inputs and expected outputs are stored:
                         (logits + gradient), and a guided 10-step DDIM loop, B=1
     full_lsun256.npz    ADM LSUN-256 dynamic UNet (552.8 M; search_lsun_cat.sh:1), B=1, with and without a skip list
                         (output stored at every second pixel: 2 x 393 KB instead of 2 x 1.5 MB)
+    full_adm256cc.npz   the same network class-conditional (554 M: search_lsun_cat.sh:1 + class_cond), B=1, with and
+                        without a skip list, every second pixel
     full_sd_v1.npz      Stable-Diffusion v1 latent UNet (859.5 M; v1-inference_coco.yaml:29-44), one 64x64 latent
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/capture_fullsize.py [name ...]
@@ -216,6 +218,24 @@ def cap_lsun256():
          out_norm=np.array(float(out.double().norm())), out_skip_norm=np.array(float(out_s.double().norm())))
 
 
+def cap_adm256cc():
+    """BASELINE configs[4] as SURVEY 8(d) writes it: search_lsun_cat.sh:1 + class_cond (554 M: label_emb on the 6-level model)."""
+    _, _, create_model_and_diffusion, _ = gd_imports()
+    flags = flags_lsun256()
+    flags["class_cond"] = True
+    m, _ = create_model_and_diffusion(**flags)
+    fill_module(m)
+    x, t, y = rnd((1, 3, 256, 256), 68), torch.tensor([612]), torch.tensor([417])
+    skip = [2, 9, 33, m.layer_num - 3]
+    with torch.no_grad():
+        out = m(x, t, y, skip_layer=[])
+        out_s = m(x, t, y, skip_layer=skip)
+    save("full_adm256cc", x=x.numpy(), t=t.numpy(), y=y.numpy(), skip=np.array(skip), layer_num=np.array(m.layer_num),
+         params=np.array(sum(p.numel() for p in m.parameters())),
+         out_sub=out[:, :, ::2, ::2].numpy(), out_skip_sub=out_s[:, :, ::2, ::2].numpy(),
+         out_norm=np.array(float(out.double().norm())), out_skip_norm=np.array(float(out_s.double().norm())))
+
+
 def cap_sd_v1():
     sys.path.insert(0, SD)
     _oc, _lc = types.ModuleType("omegaconf"), types.ModuleType("omegaconf.listconfig")
@@ -234,7 +254,7 @@ def cap_sd_v1():
     save("full_sd_v1", x=x.numpy(), t=t.numpy(), context=ctx.numpy(), out=out.numpy())
 
 
-ALL = dict(adm64=cap_adm64, clf64=cap_clf64, loop64=cap_loop64, adm128=cap_adm128, lsun256=cap_lsun256, sd_v1=cap_sd_v1)
+ALL = dict(adm64=cap_adm64, clf64=cap_clf64, loop64=cap_loop64, adm128=cap_adm128, lsun256=cap_lsun256, adm256cc=cap_adm256cc, sd_v1=cap_sd_v1)
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(ALL)):

@@ -85,3 +85,63 @@ def test_rank_cpu_slice_follows_the_gpu_numa_node():
     assert all(len(g) == 32 and len(k) == 16 for g, k in zip(smt, cores))
     assert all(not (cores[i] & cores[j]) for i in range(8) for j in range(i))
     assert all(set(smt[r]) <= set(s0 if r < 4 else s1) for r in range(8))
+
+
+def test_bare_gpus_n_launches_itself_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the driver's own command shape) becomes the launcher: the ranks start as a
+    torchrun CHILD process with a clean rendezvous environment, and bench.py exits with the child's code.  No HIP call precedes it
+    (this test runs without a GPU: main() must reach self_launch without touching torch.cuda)."""
+    import subprocess
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_PORT", "1")          # a stale rendezvous variable must not leak into the children
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "2", "--dist-backend", "gloo"])
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: (_ for _ in ()).throw(AssertionError("GPU touched before the launch")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "2", "--dist-backend", "gloo"]
+    assert "MASTER_PORT" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_world_size_mismatch_is_an_error(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_merge_policy_scales_with_the_image_area_and_graph_auto_looks_at_the_merged_pass():
+    from autodiffusion_amd.evaluate import graph_auto, merge_policy, pass_cap
+    assert (pass_cap(64), pass_cap(128), pass_cap(256), pass_cap(512)) == (256, 128, 64, 16)
+    assert merge_policy(64, 100) == (2, 200) and merge_policy(64, 256) == (1, 256) and merge_policy(64, 300) == (1, 300)
+    assert merge_policy(128, 32) == (4, 128) and merge_policy(128, 16) == (8, 128)      # the reference's 128x128 batches: 128 images per pass, not 256
+    assert merge_policy(256, 36) == (1, 36) and merge_policy(256, 16) == (4, 64)
+    assert merge_policy(128, 32, requested=8) == (8, 256) and merge_policy(128, 32, 0, rounds=2) == (2, 64)
+    assert graph_auto(64, 200) and not graph_auto(64, 300)          # batch 100 x 2 replays graphs; 3 x 100 does not
+    assert graph_auto(128, 64) and not graph_auto(128, 128) and not graph_auto(256, 36)
+    assert graph_auto(256, 16)
+
+
+def test_secondary_lines_keep_the_numbers_and_drop_the_prose():
+    line = {"metric": "m", "value": 1.5, "unit": "images/sec", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 10.0, "scaling": "weak",
+            "dtype": "bf16", "data": "long prose", "config": {"workload": "w", "global_batch": 64}, "model_tflops": 3.0,
+            "roofline": {"bound": "mfma", "kernel": "k", "achieved": 1.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.0004, "launches": 3,
+                         "avg_launch_us": 1.0, "avg_launch_gflop": 2.0, "traffic_source": "prose", "how": "prose"},
+            "output_check": {"finite": True, "how": "prose"}, "cpu_baseline": {"value": 1}, "hbm_peak_gb": 2.0}
+    c = bench.compact(line)
+    assert c["value"] == 1.5 and c["workload"] == "w" and c["roofline"]["frac"] == 0.0004 and c["hbm_peak_gb"] == 2.0
+    assert "data" not in c and "cpu_baseline" not in c and "how" not in c["roofline"] and c["output_check"] == {"finite": True}

@@ -1,5 +1,6 @@
 """FID statistics: Frechet distance (product and oracle) against analytic cases and a direct scipy
 evaluation; pooled statistics over 2 ranks (gloo, CPU); GPU accumulation vs numpy float64."""
+import json
 import os
 import socket
 
@@ -108,6 +109,34 @@ def test_pooled_statistics_two_ranks_gloo(tmp_path):
     acts = np.random.default_rng(100).standard_normal((37, d))
     np.testing.assert_allclose(z["mu"], acts.mean(0), rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(z["sigma"], np.cov(acts, rowvar=False), rtol=1e-10, atol=1e-12)
+
+
+def _forced_world1_main(rank, port, d, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ADM_FORCE_COLLECTIVES="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    acts = np.random.default_rng(5).standard_normal((9, d))
+    acc = ActivationAccumulator(d, "cpu")
+    acc.n, acc.s1, acc.s2 = 9, torch.from_numpy(acts.sum(0)), torch.from_numpy(acts.T @ acts)
+    st = acc.statistics()
+    np.savez(out, mu=st.mu, sigma=st.sigma, coll=json.dumps(acc.last_collective))
+    os.environ["ADM_FORCE_COLLECTIVES"] = "0"
+    acc.last_collective = None
+    acc.statistics()
+    assert acc.last_collective is None          # the single-rank short-cut again
+    dist.destroy_process_group()
+
+
+def test_forced_world_size_one_group_runs_the_all_gather(tmp_path):
+    """ADM_FORCE_COLLECTIVES=1 (bench.py --force-dist): a one-rank group still takes pooled() through the process group -- the switch
+    the GPU box uses to run the 32 MiB all_gather on RCCL (tests/test_hip_rccl.py); here on gloo."""
+    import torch.multiprocessing as mp
+    d, out = 5, str(tmp_path / "w1.npz")
+    mp.spawn(_forced_world1_main, args=(_free_port(), d, out), nprocs=1, join=True)
+    z = np.load(out)
+    acts = np.random.default_rng(5).standard_normal((9, d))
+    np.testing.assert_allclose(z["sigma"], np.cov(acts, rowvar=False), rtol=1e-10, atol=1e-12)
+    assert json.loads(str(z["coll"])) == {"op": "all_gather", "backend": "gloo", "world_size": 1, "bytes_per_rank": 8 * (1 + d + d * d), "device": "cpu"}
 
 
 def test_accumulator_refuses_host_activations():

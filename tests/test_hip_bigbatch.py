@@ -83,27 +83,36 @@ def test_adm64_batch_256_equals_the_batch_2_evaluation_bitwise():
     assert h[8] >= 0.99 and h[2] >= 0.90, h
 
 
-def test_lsun256_batch_64_equals_the_batch_1_evaluation_bitwise():
+@pytest.mark.parametrize("fixture,class_cond", [("full_lsun256", False), ("full_adm256cc", True)])
+def test_lsun256_batch_64_equals_the_batch_1_evaluation_bitwise(fixture, class_cond):
     """The 256x256 bench line's batch (64; one bf16 activation of the first level is 2.1 GB > 2^31 bytes): rows of the big
-    batch bitwise equal to their own B = 1 evaluations, the fixture row within tolerance of the reference."""
+    batch bitwise equal to their own B = 1 evaluations, the fixture row within tolerance of the reference -- for the
+    unconditional LSUN network and for the class-conditional one BASELINE configs[4] names."""
     from bench import adm256_flags
     from autodiffusion_amd.script_util import create_model_and_diffusion
     B = 64
-    g = golden("full_lsun256")
-    model, _ = create_model_and_diffusion(**adm256_flags())
+    g = golden(fixture)
+    flags = adm256_flags()
+    flags["class_cond"] = class_cond
+    model, _ = create_model_and_diffusion(**flags)
     load_filled(model)
     x1, t1 = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
     xb, tb = _pad_batch(x1, B, 41, "normal"), _pad_batch(t1, B, 42, "repeat")
     xb_d, tb_d = xb.to(DEV), tb.to(DEV)
+    y1 = yb_d = None
+    if class_cond:
+        y1 = torch.from_numpy(g["y"]).to(DEV)
+        yb_d = torch.cat([y1, torch.randint(0, 1000, (B - 1,), generator=torch.Generator().manual_seed(43)).to(DEV)])
+    row = lambda v, i: None if v is None else v[i:i + 1]   # noqa: E731
     for tag, skip in (("out", []), ("out_skip", g["skip"].tolist())):
-        outb = model(xb_d, tb_d, None, skip_layer=skip)
-        out1 = model(x1.to(DEV), t1.to(DEV), None, skip_layer=skip)
+        outb = model(xb_d, tb_d, yb_d, skip_layer=skip)
+        out1 = model(x1.to(DEV), t1.to(DEV), y1, skip_layer=skip)
         r = rel(out1[:, :, ::2, ::2], g[f"{tag}_sub"])
         k = x1.shape[0]
-        print(f"LSUN-256 UNet ({tag}): B={k} vs reference {r:.3e}; B=64 rows [0:{k}] bitwise equal: {torch.equal(outb[:k], out1)}")
+        print(f"{fixture} UNet ({tag}): B={k} vs reference {r:.3e}; B=64 rows [0:{k}] bitwise equal: {torch.equal(outb[:k], out1)}")
         assert r < 2e-2 and torch.isfinite(outb).all()
         assert torch.equal(outb[:k], out1)
         for i in (37, B - 1):
-            assert torch.equal(model(xb_d[i:i + 1], tb_d[i:i + 1], None, skip_layer=skip), outb[i:i + 1]), (tag, i)
+            assert torch.equal(model(xb_d[i:i + 1], tb_d[i:i + 1], row(yb_d, i), skip_layer=skip), outb[i:i + 1]), (tag, i)
         del outb
     torch.cuda.empty_cache()

@@ -224,6 +224,34 @@ def test_lsun256_dynamic_unet_matches_the_reference():
     assert r16 < 4e-3, r16
 
 
+def test_adm256_class_conditional_dynamic_unet_matches_the_reference():
+    """BASELINE configs[4] AS WRITTEN (search_lsun_cat.sh:1 + class_cond): the 553.8 M-parameter class-conditional
+    256x256 dynamic UNet -- `label_emb` (unet.py:476-478, 652-654) on the 6-level model -- with and without a layer-skip list."""
+    from bench import adm256_flags
+    from autodiffusion_amd.script_util import create_model_and_diffusion
+    g = golden("full_adm256cc")
+    flags = adm256_flags()
+    flags["class_cond"] = True
+    model, _ = create_model_and_diffusion(**flags)
+    load_filled(model)
+    assert model.layer_num == int(g["layer_num"]) and sum(p.numel() for p in model.parameters()) == int(g["params"])
+    x, t, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "y"))
+    for tag, skip in (("out", []), ("out_skip", g["skip"].tolist())):
+        out = model(x, t, y, skip_layer=skip)
+        r = rel(out[:, :, ::2, ::2], g[f"{tag}_sub"])
+        rn = abs(float(out.double().norm()) / float(g[f"{tag}_norm"]) - 1.0)
+        print(f"full class-conditional ADM-256 UNet ({tag}): rel {r:.3e}, norm ratio off by {rn:.3e}")
+        assert torch.isfinite(out).all() and r < 2e-2 and rn < 1e-2, (tag, r, rn)
+    # the label matters (another class: another output) and the unconditional call is refused, as in the reference (unet.py:644-646)
+    other = model(x, t, (y + 1) % 1000, skip_layer=[])
+    assert rel(other[:, :, ::2, ::2], g["out_sub"]) > 1e-3
+    with pytest.raises((AssertionError, ValueError)):
+        model(x, t, None, skip_layer=[])
+    r16 = rel(model.set_torso("fp16")(x, t, y)[:, :, ::2, ::2], g["out_sub"])
+    print(f"full class-conditional ADM-256 UNet, fp16 torso: rel {r16:.3e}")
+    assert r16 < 4e-3, r16
+
+
 def test_sd_v1_latent_unet_matches_the_reference():
     """BASELINE config 4's network (v1-inference_coco.yaml:29-44): the 859.5 M-parameter latent UNet (320/640/1280
     channels, 40/80/160-wide heads, 77 x 768 context) on one 64x64 latent."""

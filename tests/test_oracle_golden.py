@@ -240,3 +240,25 @@ def test_oracle_at_baseline_size_matches_the_reference_captures():
     grad = nets.classifier_grad(Pc, cplan, T(gc["x"]), T(gc["t"]), T(gc["y"]), 1.0)
     r = float((grad - T(gc["grad"])).norm() / T(gc["grad"]).norm())
     assert r < 1e-3, r
+
+
+def test_oracle_class_conditional_256_matches_the_reference_capture():
+    """BASELINE configs[4] as written (search_lsun_cat.sh:1 + class_cond, 553.8 M parameters): the oracle's dynamic UNet with
+    `label_emb` on the 6-level model against the reference's own output, with and without a layer-skip list (every second pixel)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import adm256_flags
+    from autodiffusion_amd.script_util import create_model_and_diffusion
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    g = golden("full_adm256cc")
+    flags = adm256_flags()
+    flags["class_cond"] = True
+    plan = create_model_and_diffusion(**flags)[0].plan
+    assert plan.layer_num == int(g["layer_num"]) and sum(int(np.prod(s)) for s in plan.param_shapes().values()) == int(g["params"])
+    P = nets.params_from_numpy(filled(plan))
+    with torch.no_grad():
+        for tag, skip in (("out", []), ("out_skip", g["skip"].tolist())):
+            out = nets.unet_forward(P, plan, T(g["x"]), T(g["t"]), T(g["y"]), skip_layer=skip)[:, :, ::2, ::2]
+            r = float((out - T(g[f"{tag}_sub"])).norm() / T(g[f"{tag}_sub"]).norm())
+            assert r < 1e-4, (tag, r)
