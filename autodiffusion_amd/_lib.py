@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("ADM_HIP_LIB") or os.path.join(_HERE, "libadm_hip.so")
 # the same kernels built with IEEE half as the 16-bit element type (csrc/adm_common.h, -DADM_ACT_F16): the reference's own
 # torso precision (use_fp16=True); selected per tensor dtype by ops.py, per model by `torso="fp16"` / ADM_TORSO=fp16
 LIB_PATH_F16 = os.environ.get("ADM_HIP_LIB_F16") or os.path.join(_HERE, "libadm_hip_f16.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class AdmError(RuntimeError):
@@ -49,6 +49,7 @@ class ConvArgs(C.Structure):
         ("in_up", C.c_int32), ("res_up", C.c_int32), ("ksplit", C.c_int32), ("ws", C.c_void_p),
         ("up_phase", C.c_int32), ("geglu", C.c_int32),
         ("fold0", C.c_void_p), ("fold1", C.c_void_p), ("fc0", C.c_int32), ("fc1", C.c_int32),
+        ("out_scale", C.c_float),
     ]
 
 
@@ -64,6 +65,10 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "adm_abi_version": (_I, []),
     "adm_last_error": (C.c_char_p, []),
+    "adm_stream_create_cumask": (_I, [_P, _I, C.POINTER(C.c_void_p)]),
+    "adm_stream_set_cus": (_I, [_P, _I]),
+    "adm_stream_destroy": (_I, [_P]),
+    "adm_stream_probe": (_I, [_P, _I, _P]),
     "adm_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(StepCoefs), _P]),
     "adm_ddpm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.POINTER(StepCoefs), _P]),
     "adm_pack_u8_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -40,8 +40,10 @@ class EncoderUNetModel(AdmNet):
     # 100 % of a tensor's elements below fp16's smallest normal (6.1e-5; tools/mixed_torso_probe.py, profiles/r03/mixed_torso_probe.log).
     # bf16 has fp32's exponent range and needs nothing.  With an fp16 torso (set_torso("fp16"): 11 mantissa bits, the guidance
     # gradient's error against the reference's autograd 2.0e-2 -> 4e-3) the whole chain is LINEAR in d(logits), so it runs on
-    # d(logits) * 2^10 -- every tensor back in the normal range, max |g| * 2^10 ~ 3, far from 65504 -- and 2^-10 is folded into the
-    # weights of the last backward conv (the stem's, AdmNet._prepare): exact, no extra pass, no dynamic loss-scale state.
+    # d(logits) * 2^10 -- every tensor back in the normal range, max |g| * 2^10 ~ 3, far from 65504 -- and the last backward conv (the
+    # stem's, which writes the fp32 NCHW gradient) multiplies by 2^-10 in its fp32 epilogue (adm_conv_args.out_scale): exact, no extra
+    # pass, no dynamic loss-scale state, and the stem's fp16 weights stay in the normal range (folding 2^-10 into THEM, as round 3
+    # did, made every |w| < 2^-4 subnormal).
     FP16_GRAD_SCALE = 1024.0
 
     @property
@@ -239,7 +241,8 @@ class EncoderUNetModel(AdmNet):
                             g = ops.gn_bwd(t["x"], d_in, t["aff1"], t["st1"], silu=True, add=dskip)
                 elif kind == "stem":
                     d = pr.blocks[s.prefix]
-                    g = ops.conv(g, d["w_bwd"], pr.zero_bias, s.cin, 9, out_f32_nchw=True)
+                    g = ops.conv(g, d["w_bwd"], pr.zero_bias, s.cin, 9, out_f32_nchw=True,
+                                 out_scale=None if self.grad_scale == 1.0 else 1.0 / self.grad_scale)
             return g
 
     def log_prob_grad(self, x, timesteps, y, scale: float = 1.0, return_logits: bool = False):
@@ -284,6 +287,6 @@ class _ClassifierFn(torch.autograd.Function):
             raise RuntimeError("the HIP classifier's activations were already released (backward called twice)")
         dl = dlogits.detach().to(torch.float32)
         if ctx.net.grad_scale != 1.0:
-            dl = dl * ctx.net.grad_scale     # undone inside the network (the stem's backward weights carry 1 / grad_scale)
+            dl = dl * ctx.net.grad_scale     # undone inside the network (the stem's backward conv scales its fp32 output by 1 / grad_scale)
         g = ctx.net._backward_tape(tape, dl.contiguous())
         return g.to(ctx.x_dtype), None, None

@@ -26,6 +26,9 @@ typedef __attribute__((ext_vector_type(4))) short adm_s16x4_t;
 
 // thread-local error text, set by ADM_FAIL / adm_check_launch
 void adm_set_error(const char* fmt, ...);
+// CUs a persistent kernel launched on `stream` may occupy: the stream's registered CU budget (adm_stream_create_cumask /
+// adm_stream_set_cus, adm_api.hip), else `dflt` (the device's CU count)
+int adm_stream_cus(void* stream, int dflt);
 
 #define ADM_FAIL(code, ...)        \
   do {                             \

@@ -101,6 +101,7 @@ struct ConvK {
   // follow the 3x3 weights in `w` (K-step index chunks * 9 + j): out = conv3x3(act(GN(h))) + conv1x1(x) + (bias3 + bias1)
   const uint16_t* f0; const uint16_t* f1;
   int FC0, FC1;
+  float out_scale;   // fp32 NCHW epilogue only (adm_conv_args.out_scale; 1 if not given)
 };
 
 // output-statistics slabs per tile: a 128-pixel tile is two 8x8 images (or two halves of one image)
@@ -371,6 +372,16 @@ conv_kernel(const ConvK p) {
     const unsigned voff = pixrel[ps] >= 0 ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
     return bufload16(rs, voff, 0);
   };
+  // the NOEXIT 1x1 loops run K-steps past the tile's last chunk (on weight fragments the descriptor returns as zeros): their
+  // ACTIVATION side reads zeros too -- 0 x Inf of a re-read, overflowed last chunk would be NaN where the exact loop gives +-Inf
+  [[maybe_unused]] auto halo_load_pad = [&](int c, int lastc, int ps) -> uint4 {
+    const int cc = min(c, lastc);
+    const bool first = cc < c0chunks;
+    const int cs = first ? p.C0 : p.C1, co = (first ? cc : cc - c0chunks) * KCS;
+    const __amdgpu_buffer_rsrc_t rs = first ? rs0 : rs1;
+    const unsigned voff = (pixrel[ps] >= 0 && c <= lastc) ? (unsigned)(pixrel[ps] * cs + co + seg * 8) * 2u : OOB;
+    return bufload16(rs, voff, 0);
+  };
   // FOLD: segment `ps` of chunk k of the skip_connection's input (same halo geometry: only its centre tap is used), and its raw park
   [[maybe_unused]] auto fold_load = [&](int k, int ps) -> uint4 {
     const int f0chunks = p.FC0 / KCS;
@@ -518,13 +529,14 @@ conv_kernel(const ConvK p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) load_w(ks, wr[ks]);  // stage 0's K-steps
       }
+      constexpr bool NOEXIT1P = KS == 1 && ADM_CONV_1X1_NOEXIT && TM == 4 && !COLD;
 #pragma unroll
-      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = halo_load(min(cb + 1, last), ps);
+      for (int ps = 0; ps < PASSES; ++ps) ring[1][ps] = NOEXIT1P ? halo_load_pad(cb + 1, last, ps) : halo_load(min(cb + 1, last), ps);
       if constexpr (DEEP1) {
 #pragma unroll
         for (int q = 2; q < RINGN; ++q) {
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) ring[q][ps] = halo_load(min(cb + q, last), ps);
+          for (int ps = 0; ps < PASSES; ++ps) ring[q][ps] = NOEXIT1P ? halo_load_pad(cb + q, last, ps) : halo_load(min(cb + q, last), ps);
         }
       }
 #if ADM_CONV_RD == 3
@@ -840,7 +852,7 @@ conv_kernel(const ConvK p) {
           // activation ring: chunk k lives in slot k % RINGN; chunk c's slot is free (parked during step c - 1)
           (void)SA;
 #pragma unroll
-          for (int ps = 0; ps < PASSES; ++ps) ring[SW % RINGN][ps] = halo_load(min(c + RINGN, last), ps);
+          for (int ps = 0; ps < PASSES; ++ps) ring[SW % RINGN][ps] = NOEXIT ? halo_load_pad(c + RINGN, last, ps) : halo_load(min(c + RINGN, last), ps);
           load_w(NOEXIT ? c + WRING - 1 : min(c + WRING - 1, last), wr[(SW + WRING - 1) % WRING]);
           mfma_tap(halo + (c & 1) * Lds::HB, wr[SW % WRING]);
 #pragma unroll
@@ -1116,7 +1128,7 @@ conv_kernel(const ConvK p) {
             const int ch = ch0 + e;
             if (ch >= p.Cout) continue;
             reinterpret_cast<float*>(p.out)[(((long long)n * p.Cout + ch) * p.H + y) * p.W + x] =
-                acc[i][j][e] + (ch0 + 3 < p.Cout ? 0.f : p.bias[ch]);
+                (acc[i][j][e] + (ch0 + 3 < p.Cout ? 0.f : p.bias[ch])) * p.out_scale;
           }
         }
       }
@@ -1489,12 +1501,13 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
   constexpr int smem = ConvLds<NT, BN, HALO, WM * TM * 16, KS>::BYTES;
   static_assert(smem <= 160 * 1024, "conv_kernel LDS map exceeds the CU's 160 KB");
   // per device: opt in to the LDS size once, and size the persistent grid to the resident blocks
-  static int slots_dev[64] = {};
+  static int percu_dev[64] = {}, ncu_dev[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  int& slots = slots_dev[dev & 63];
+  int& per_cu_d = percu_dev[dev & 63];
+  int& ncu_d = ncu_dev[dev & 63];
   const void* fn = reinterpret_cast<const void*>(&conv_kernel<WM, WN, TM, TN, OCC, TAPS, HALO, PRO, KS, COLD>);
-  if (slots == 0) {
+  if (per_cu_d == 0) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) ADM_FAIL((int)e, "adm_conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
     int per_cu = 0, ncu = 0;
@@ -1502,8 +1515,12 @@ int launch_conv_p(const ConvK& k, int m_tiles, hipStream_t s) {
     if (e != hipSuccess || per_cu <= 0) ADM_FAIL((int)e, "adm_conv: block of %d threads / %d B LDS is not launchable", NT, smem);
     e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess || ncu <= 0) ADM_FAIL((int)e, "adm_conv: hipDeviceGetAttribute: %s", hipGetErrorString(e));
-    slots = per_cu * ncu;
+    ncu_d = ncu;
+    per_cu_d = per_cu;
   }
+  // a CU-masked stream owns fewer CUs: the persistent grid is sized to those (result-neutral: a tile's arithmetic does not depend
+  // on which block of the grid walks it)
+  const int slots = per_cu_d * adm_stream_cus((void*)s, ncu_d);
   ConvK kk = k;
   kk.nbp = (k.Cout + BN - 1) / BN;
   kk.nblocks_n = kk.nbp * (k.nph > 1 ? k.nph : 1);
@@ -1716,6 +1733,7 @@ extern "C" int adm_conv(const adm_conv_args* a, void* stream) {
   k.stats = a->out_stats; k.stat_slabs = 0;
   k.N = a->n; k.H = a->h; k.W = a->w; k.C0 = a->c0; k.C1 = a->c1; k.Cout = a->cout;
   k.out_mode = a->out_mode;
+  k.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
   k.in_up = a->in_up ? 1 : 0;
   k.res_up = a->res_up ? 1 : 0;
   ADM_REQUIRE(!(k.in_up || k.res_up) || (a->taps == 9 && a->out_mode == 0 && a->c1 == 0 && a->h % 2 == 0 && a->w % 2 == 0 && a->h >= 16 && a->w >= 16),

@@ -416,7 +416,8 @@ int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
     if (e != hipSuccess || ncu <= 0) ADM_FAIL((int)e, "adm_conv: hipDeviceGetAttribute: %s", hipGetErrorString(e));
     slots = ncu;  // one block per CU: the resident tile takes most of the LDS
   }
-  const unsigned blocks = (unsigned)(k.m_tiles < slots ? k.m_tiles : slots);
+  const int mine = adm_stream_cus((void*)s, slots);   // a CU-masked stream: one block per CU it owns
+  const unsigned blocks = (unsigned)(k.m_tiles < mine ? k.m_tiles : mine);
   hipLaunchKernelGGL((conv1x1r_kernel<BM, PRO, WP, WM, GG>), dim3(blocks), dim3(512), smem, s, k);
   return adm_check_launch("adm_conv");
 }
@@ -427,7 +428,7 @@ int launch_c1(const Conv1K& k, int smem, hipStream_t s) {
 // rows (1: 384-wide Cout blocks; 2: 192-wide, for narrow outputs); returns 0 otherwise
 int adm_conv1x1_resident_cfg(const adm_conv_args* a, int* wm_out) {
   static const bool disabled = getenv("ADM_CONV_NO_RESIDENT") != nullptr;  // A/B switch for measurements
-  if (disabled && a->variant == 0) return 0;
+  if (disabled && a->variant == 0 && !a->geglu) return 0;   // the GEGLU epilogue exists on this kernel only: the switch leaves it here
   if (a->taps != 1 || a->out_mode != 0 || (a->variant != 0 && a->variant != 10) || a->ksplit > 1) return 0;   // split-K: the staged kernel
   const int k = a->c0 + a->c1, hw = a->h * a->w;
   if (k % 64 != 0 || a->c0 % 8 != 0 || a->c1 % 8 != 0 || a->cout % 8 != 0 || hw % 64 != 0) return 0;

@@ -75,6 +75,26 @@ def frechet_distance_device(mu1: torch.Tensor, sigma1: torch.Tensor, mu2: torch.
     return float(diff.dot(diff) + torch.trace(sigma1) + torch.trace(sigma2) - 2 * ev.clamp_min(0).sqrt().sum())
 
 
+def frechet_distance_lowrank(acts: torch.Tensor, mu2: torch.Tensor, sigma2: torch.Tensor) -> float:
+    """The same quantity from the n < dim activation rows themselves (float64 on their device).
+
+    With n samples in d dimensions, S1 = Xc^T Xc / (n - 1) has rank <= n - 1 and the non-zero eigenvalues of S1 S2 are those of the
+    n x n matrix Xc S2 Xc^T / (n - 1) (cyclic invariance), so tr sqrtm(S1 S2) = sum sqrt(eig(Xc S2 Xc^T / (n - 1))): one
+    [n, d] x [d, d] x [d, n] product and an n x n symmetric eigenproblem instead of two d x d ones -- 64 x 64 instead of 2048 x 2048
+    for BASELINE config 3's 64-image candidates (the search's regime: `num_samples <= 1000`, GD/README.md:22).  Equal to
+    frechet_distance_device to ~1e-8 relative (that form also sums the square roots of the rounding-level eigenvalues of the
+    d - n + 1 null directions; tests/test_fid.py)."""
+    x = acts.to(torch.float64)
+    n = x.shape[0]
+    mu1 = x.mean(0)
+    xc = x - mu1
+    mu2, sigma2 = mu2.to(torch.float64), sigma2.to(torch.float64)
+    m = (xc @ sigma2 @ xc.T) / (n - 1)
+    ev = torch.linalg.eigvalsh((m + m.T) * 0.5)
+    diff = mu1 - mu2
+    return float(diff.dot(diff) + (xc * xc).sum() / (n - 1) + torch.trace(sigma2) - 2 * ev.clamp_min(0).sqrt().sum())
+
+
 def compute_statistics(activations: np.ndarray) -> FIDStatistics:
     """Host form (np.mean / np.cov), used when the activations already live on the host."""
     return FIDStatistics(np.mean(activations, axis=0), np.cov(activations, rowvar=False))
@@ -83,9 +103,14 @@ def compute_statistics(activations: np.ndarray) -> FIDStatistics:
 class ActivationAccumulator:
     """Running (n, sum a, sum a a^T) of fp32 activations; float64 on the device that produces them."""
 
-    def __init__(self, dim: int, device):
+    def __init__(self, dim: int, device, keep_rows: int = 0):
+        """keep_rows > 0: also keep the activation rows themselves while there are at most that many (callers that know the candidate
+        has fewer samples than dimensions: frechet_distance_device then takes the n x n form, frechet_distance_lowrank)."""
         self.dim = dim
         self.device = torch.device(device)
+        self.keep_rows = int(keep_rows)
+        self.rows = [] if keep_rows > 0 else None
+        self._ref_dev = None    # (id(ref), mu, sigma) of the last reference statistics, on the device
         self.n = 0
         self.s1 = torch.zeros(dim, dtype=torch.float64, device=self.device)
         self.s2 = torch.zeros(dim, dim, dtype=torch.float64, device=self.device)
@@ -140,6 +165,11 @@ class ActivationAccumulator:
         check(lib.adm_fid_accumulate(acts.data_ptr(), self.s1.data_ptr(), self.s2.data_ptr(), acts.shape[0],
                                      self.dim, torch.cuda.current_stream().cuda_stream), "adm_fid_accumulate")
         self.n += int(acts.shape[0])
+        if self.rows is not None:
+            if self.n <= self.keep_rows:
+                self.rows.append(acts.clone())
+            else:
+                self.rows = None            # more rows than announced: the Gram form serves
 
     def pooled(self, group=None, local=False):
         """(n, s1, s2) summed over ranks (local=True: this rank's sums only -- population-parallel mode): ONE all_gather per candidate of one packed float64 buffer
@@ -182,13 +212,20 @@ class ActivationAccumulator:
 
     def frechet_distance_device(self, ref: FIDStatistics, group=None, local=False) -> float:
         """FID against host reference statistics without the activations' sums leaving the device."""
+        from .dist_util import collectives_on
+        if self._ref_dev is None or self._ref_dev[0] is not ref:     # one upload of the 32 MiB reference covariance per accumulator
+            self._ref_dev = (ref, torch.as_tensor(np.asarray(ref.mu), dtype=torch.float64, device=self.device),
+                             torch.as_tensor(np.asarray(ref.sigma), dtype=torch.float64, device=self.device))
+        _, rmu, rsig = self._ref_dev
+        if self.rows is not None and 2 <= self.n < self.dim and (local or not collectives_on(group)):
+            self.join()
+            # fewer samples than dimensions, all of them on this rank: the n x n eigenproblem (same value, float64)
+            return frechet_distance_lowrank(torch.cat(self.rows, 0), rmu, rsig)
         n, s1, s2 = self.pooled(group, local)
         if n < 2:
             raise ValueError("need at least 2 activations for a covariance")
         mu = s1 / n
         sigma = (s2 - n * torch.outer(mu, mu)) / (n - 1)
-        rmu = torch.as_tensor(np.asarray(ref.mu), dtype=torch.float64, device=self.device)
-        rsig = torch.as_tensor(np.asarray(ref.sigma), dtype=torch.float64, device=self.device)
         return frechet_distance_device(mu, sigma, rmu, rsig)
 
 

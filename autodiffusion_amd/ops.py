@@ -300,7 +300,7 @@ def splitk_1x1_for(h: int, w: int, cin: int, cout: int) -> int:
 
 def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True, res=None,
          out_f32_nchw=False, variant=0, out=None, w_packed32=None, want_stats=False, in_up=False, res_up=False, ksplit=1,
-         w_up=None, gnb=None, geglu=False, fold=None):
+         w_up=None, gnb=None, geglu=False, fold=None, out_scale=None):
     """Fused [GN(+FiLM) affine (+SiLU)] -> conv (3x3 pad 1 | 1x1) -> +bias (+res).
 
     x0 (| x1): 16-bit NHWC (bf16, or fp16 for an fp16-torso model: the library is picked by x0's dtype).  Returns the same
@@ -312,6 +312,7 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
     value * gelu(gate) -- the Stable-Diffusion GEGLU without the [.., cout] tensor (1x1 resident-tile kernel only).
     fold=(xs0, xs1 | None): the ResBlock's skip_connection inside this (out_layers) conv: w_packed = fold_weights(3x3, 1x1), bias = the
     sum of both biases; extra one-tap K-steps over the block input (xs0 | xs1) replace the 1x1 launch and the residual operand.
+    out_scale: fp32 NCHW output only -- (acc + bias) * out_scale in the fp32 epilogue.
     """
     n, h, w, c0 = x0.shape
     if (in_up and w_up is not None and UPCONV_PHASES and taps == 9 and x1 is None and res is None and not res_up
@@ -328,6 +329,10 @@ def conv(x0, w_packed, bias, cout: int, taps: int, x1=None, aff=None, silu=True,
                else torch.empty((n, h, w, cout // 2 if geglu else cout), dtype=x0.dtype, device=dev))
     a = ConvArgs()
     a.geglu = int(bool(geglu))
+    if out_scale is not None:
+        if not out_f32_nchw:
+            raise AdmError("conv(out_scale=...): the fp32 NCHW epilogue only")
+        a.out_scale = float(out_scale)
     lib = _L(x0)
     a.in0, a.in1 = _ptr(x0, x0.dtype, "x0"), _ptr(x1, x0.dtype, "x1")
     a.w_packed, a.bias = _ptr(w_packed, x0.dtype, "w_packed"), _ptr(bias, torch.float32, "bias")

@@ -8,6 +8,7 @@ condition_score / condition_mean + the x_{t-1} update is ONE launch of
 ``adm_ddim_step`` / ``adm_ddpm_step``; the model and cond_fn stay arbitrary
 callables ``(x, t_mapped, **model_kwargs)`` exactly as in the reference.
 
+``denoised_fn`` (applied to the predicted x_0 before the clip, :293-298) is honoured with two launches around the caller's function.
 Training-time members (q_sample, training_losses, bpd, ddim_reverse_sample) are
 out of scope: candidate evaluation never calls them.
 """
@@ -58,6 +59,44 @@ def step_coefs(tables, i: int, *, learned_range: bool, fixed: str = "large", pre
 
 
 _SIDE_STREAMS = {}  # device -> second HIP stream for the guidance gradient (kept out of the deep-copied objects)
+_PARTITIONS = {}    # (device, spec) -> (UNet stream, guidance stream, description) | None
+
+
+def cu_partition(device, spec: str):
+    """Two CU-MASKED HIP streams for one guided step: the UNet on one part of the chip, the guidance gradient on the rest.
+
+    Both networks' hot kernels are persistent one-block-per-CU kernels that fill a CU's LDS and registers, so on two ordinary
+    streams they time-share every CU (the second stream only fills the first one's tails); on masked streams each runs undisturbed
+    on its own CUs, and the memory-bound stretches of the gradient network leave their power budget to the other part's matrix
+    cores.  spec = "G": G CUs (a multiple of 8: G / 8 of every XCD) go to the guidance stream, the rest to the UNet.  Results do
+    not depend on the partition.  -> (unet_stream, guide_stream, description)."""
+    key = (torch.device(device).index, spec)
+    if key in _PARTITIONS:
+        return _PARTITIONS[key]
+    import ctypes as C
+    from . import _lib
+    g = int(spec)
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    if not (0 < g < ncu) or g % 8 or (ncu - g) % 8:
+        raise ValueError(f"ADM_CU_PARTITION={spec!r}: expected a multiple of 8 with 0 < G < {ncu}")
+    # mask bit i is CU i // 8 of XCD i % 8 (tools/cumask_probe.py on this pool: the driver deals the bits round-robin over the 8
+    # XCDs, and a mask that leaves an XCD without a CU is ignored altogether): the top G bits = the last G / 8 CUs of EVERY XCD, so
+    # both streams keep all 8 L2s and the kernels' `blockIdx & 7` XCD labels stay valid
+    guide_bits = set(range(ncu - g, ncu))
+    words = (ncu + 31) // 32
+
+    def mk(bits):
+        m = (C.c_uint32 * words)()
+        for i in bits:
+            m[i // 32] |= 1 << (i % 32)
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().adm_stream_create_cumask(m, words, C.byref(out)), "adm_stream_create_cumask")
+        return torch.cuda.ExternalStream(out.value, device=device)
+    unet_s, guide_s = mk(set(range(ncu)) - guide_bits), mk(guide_bits)
+    desc = f"CU-partitioned streams: UNet on {ncu - g} CUs, guidance gradient on {g} CUs ({g // 8} of every XCD's 32)"
+    _PARTITIONS[key] = (unet_s, guide_s, desc)
+    return _PARTITIONS[key]
 
 
 class SpacedDiffusion:
@@ -66,6 +105,13 @@ class SpacedDiffusion:
     # eps(x_t) and the classifier-guidance gradient run concurrently on two HIP streams (bit-identical results;
     # ADM_OVERLAP_GUIDANCE=0 or setting the attribute to False restores the sequential order)
     overlap_guidance = os.environ.get("ADM_OVERLAP_GUIDANCE", "1") != "0"
+    # "G": give the guidance gradient G CUs of its own and the UNet the rest (cu_partition); "" = two ordinary streams
+    cu_partition_spec = os.environ.get("ADM_CU_PARTITION", "")
+
+    def describe_overlap(self):
+        if self.cu_partition_spec and self.overlap_guidance:
+            return "timed region: " + cu_partition(torch.cuda.current_device(), self.cu_partition_spec)[2]
+        return "timed region: UNet and classifier-guidance kernels overlap on two HIP streams"
 
     def __init__(self, use_timesteps, *, betas, model_mean_type, model_var_type, loss_type,
                  rescale_timesteps=False):
@@ -103,8 +149,6 @@ class SpacedDiffusion:
 
     def _step(self, kind, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
               want_u8=False, index=None):
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn breaks the fused per-pixel update; no reference script uses it")
         if model_kwargs is None:
             model_kwargs = {}
         if index is None:  # direct p_sample / ddim_sample calls: read the index back from the tensor
@@ -116,7 +160,25 @@ class SpacedDiffusion:
         ts = self._mapped(t)
         x = x.contiguous()
         grad = None
-        if cond_fn is not None and self.overlap_guidance and x.is_cuda:
+        if cond_fn is not None and self.overlap_guidance and x.is_cuda and self.cu_partition_spec:
+            # the two networks on disjoint sets of CUs (cu_partition): both depend on x_t only
+            cur = torch.cuda.current_stream(x.device)
+            unet_s, guide_s, _ = cu_partition(x.device, self.cu_partition_spec)
+            unet_s.wait_stream(cur)
+            guide_s.wait_stream(cur)
+            with torch.cuda.stream(guide_s):
+                grad = cond_fn(x, ts, **model_kwargs).float().contiguous()
+            with torch.cuda.stream(unet_s):
+                model_out = model(x, ts, **model_kwargs)
+                if model_out.dtype != torch.float32:
+                    model_out = model_out.float()
+            cur.wait_stream(unet_s)
+            cur.wait_stream(guide_s)
+            grad.record_stream(cur)
+            model_out.record_stream(cur)
+            x.record_stream(unet_s)
+            x.record_stream(guide_s)
+        elif cond_fn is not None and self.overlap_guidance and x.is_cuda:
             # eps(x_t) and the guidance gradient both depend on x_t only: the gradient runs on a second HIP stream
             # and fills the dispatch gaps and tile-quantisation tails of the UNet's ~2000 launches (and vice versa)
             cur = torch.cuda.current_stream(x.device)
@@ -145,8 +207,24 @@ class SpacedDiffusion:
             noise = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=self.generator)
         else:
             noise = torch.randn_like(x)
-        sample, x0, u8 = ops.sampler_step(kind, x, model_out.contiguous(), self._coefs(i, clip_denoised, eta),
-                                          grad, noise, want_xstart=True, want_u8=want_u8)
+        coefs = self._coefs(i, clip_denoised, eta)
+        model_out = model_out.contiguous()
+        if denoised_fn is not None:
+            # process_xstart (gaussian_diffusion.py:293-298): the caller's function acts on the predicted x_0 BEFORE the clip, in the
+            # middle of what is otherwise one fused launch.  Two launches around it (no reference script passes one): the first,
+            # unclipped and unguided, only yields x_0 = sqrt(1/abar) x - sqrt(1/abar - 1) eps; the second takes denoised_fn(x_0) as
+            # a START_X model output -- the kernel's predict_xstart path is exactly `process_xstart(model_output)` followed by the
+            # same posterior / guidance / update arithmetic (:299-306, :381-393)
+            c = x.shape[1]
+            if coefs.predict_xstart:
+                x0_raw = model_out[:, :c]
+            else:
+                probe = self._coefs(i, False, 0.0)   # unclipped, eta 0, no guidance, no noise: the ddim kernel's pred_xstart output IS that x_0
+                _, x0_raw, _ = ops.sampler_step("ddim", x, model_out, probe, None, None, want_xstart=True)
+            x0_fn = denoised_fn(x0_raw).to(torch.float32)
+            model_out = torch.cat([x0_fn, model_out[:, c:]], 1).contiguous() if coefs.learned_range else x0_fn.contiguous()
+            coefs.predict_xstart = 1
+        sample, x0, u8 = ops.sampler_step(kind, x, model_out, coefs, grad, noise, want_xstart=True, want_u8=want_u8)
         out = {"sample": sample, "pred_xstart": x0}
         if want_u8:
             out["uint8_nhwc"] = u8

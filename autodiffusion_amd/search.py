@@ -86,6 +86,7 @@ class EvolutionSearcher(object):
         self.population_parallel = population_parallel
         self._pending = []
         self.last_flush = None
+        self._ref_dev = None     # (ref_stats, mu, sigma on the device): uploaded once, not once per candidate
         self._ev = None
         if model is not None:
             self._ev = CandidateEvaluator(
@@ -115,7 +116,12 @@ class EvolutionSearcher(object):
         t1 = time.time()
         logger.log("sampling...")
         seed0 = (int(getattr(args, "seed", 0)) * 1000003 + zlib.crc32(str(cand).encode())) & 0x7FFFFFFF
-        acc = ActivationAccumulator(self.feature_dim, self._ev.device) if self.features is not None else None
+        # fewer samples than feature dimensions (the search's regime, `num_samples <= 1000` against 2048): the on-device Frechet
+        # distance can work from the rows (an n x n eigenproblem instead of two 2048 x 2048 ones)
+        keep = int(args.num_samples) if (getattr(args, "fid_on_device", False) and args.num_samples < self.feature_dim) else 0
+        acc = ActivationAccumulator(self.feature_dim, self._ev.device, keep_rows=keep) if self.features is not None else None
+        if acc is not None and self._ref_dev is not None and self._ref_dev[0] is self.ref_stats:
+            acc._ref_dev = self._ref_dev       # the reference statistics stay on the device across candidates
         host_images = []
         produced = 0
         batch_idx = 0
@@ -152,6 +158,7 @@ class EvolutionSearcher(object):
         if acc is not None:
             if getattr(args, "fid_on_device", False):
                 fid = acc.frechet_distance_device(self.ref_stats, None, local=local)  # eigh on the GPU instead of the host sqrtm
+                self._ref_dev = acc._ref_dev
             else:
                 fid = float(acc.statistics(None, local=local).frechet_distance(self.ref_stats))
         else:

@@ -184,6 +184,21 @@ class _Prep:
     pass
 
 
+def _graph_pool_bytes(graph, dev, reserved0, free0) -> int:
+    """Bytes of the private allocator pool a just-captured graph owns: the segments tagged with the graph's pool id in the caching
+    allocator's snapshot; if the snapshot does not tell (older / newer torch), the growth of reserved memory or the drop of free
+    device memory across the capture, whichever is larger."""
+    try:
+        pid = tuple(graph.pool())
+        got = sum(seg["total_size"] for seg in torch.cuda.memory_snapshot() if tuple(seg.get("segment_pool_id", (0, 0))) == pid
+                  and seg.get("device", dev.index) == dev.index)
+        if got > 0:
+            return int(got)
+    except Exception:
+        pass
+    return int(max(0, torch.cuda.memory_reserved(dev) - reserved0, free0 - torch.cuda.mem_get_info(dev)[0]))
+
+
 class AdmNet(HipModule):
     """Blocks shared by the UNet and the classifier half-UNet."""
 
@@ -262,7 +277,8 @@ class AdmNet(HipModule):
         """What the replay path holds: bench.py puts it on the JSON line of a --graph run."""
         graphs = getattr(self._packed, "graphs", None) if getattr(self, "_packed", None) is not None else None
         nb = [e[3] for e in graphs.values()] if graphs else []
-        return {"cached_graphs": len(nb), "pool_gb_total": round(sum(nb) / 1e9, 2), "pool_gb_largest": round(max(nb) / 1e9, 2) if nb else 0.0,
+        return {"cached_graphs": len(nb), "pool_gb_total": round(sum(nb) / 1e9, 3), "pool_gb_largest": round(max(nb) / 1e9, 3) if nb else 0.0,
+                "pool_bytes_largest": max(nb) if nb else 0, "pool_gb_of_a_capture": round(self._pool_bytes_seen / 1e9, 3),
                 "budget_gb": round(self._graph_budget() / 1e9, 1), "planned_distinct_sets": self._planned_sets,
                 "eager_fallback": bool(self._graph_eager)}
 
@@ -284,11 +300,11 @@ class AdmNet(HipModule):
                 for _ in range(2):
                     fn(*static_in)
             cur.wait_stream(side)
-            reserved0 = torch.cuda.memory_reserved(dev)
+            reserved0, free0 = torch.cuda.memory_reserved(dev), torch.cuda.mem_get_info(dev)[0]
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = fn(*static_in)
-            pool = max(0, torch.cuda.memory_reserved(dev) - reserved0)   # the capture's private pool: fresh segments, never shared
+            pool = _graph_pool_bytes(graph, dev, reserved0, free0)
             self._pool_bytes_seen = max(self._pool_bytes_seen, pool)
             entry = graphs[key] = (graph, static_in, out, pool)
             budget = self._graph_budget()
@@ -379,9 +395,9 @@ class AdmNet(HipModule):
                 p = b.prefix
                 d = pr.blocks[p]
                 if isinstance(b, StemSpec):
-                    # the LAST backward-data conv: 1 / grad_scale folded into its weights (exact: a power of two), see
-                    # EncoderUNetModel.grad_scale -- the fp16 backward network runs on d(logits) scaled up by it
-                    d["w_bwd"] = pack_bwd(P[f"{p}.weight"] * (1.0 / self.grad_scale))
+                    # the LAST backward-data conv: it undoes EncoderUNetModel.grad_scale in its fp32 epilogue (adm_conv_args.out_scale),
+                    # not in these 16-bit weights -- 2^-10 would push every |w| < 2^-4 of an fp16 image below the smallest normal
+                    d["w_bwd"] = pack_bwd(P[f"{p}.weight"])
                     zmax = max(zmax, b.cin, b.cout)
                 elif isinstance(b, ResBlockSpec):
                     d["w1_bwd"] = pack_bwd(P[f"{p}.in_layers.2.weight"])

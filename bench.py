@@ -58,11 +58,11 @@ GFLOP_GUIDE_128 = 93.0                     # 128x128 classifier (depth 2): 46.5 
 def pmc_traffic(workload):
     """(HBM bytes per launch of the workload's dominant kernel, where the figure comes from).  PMC counters cannot be read
     inside the timed run: the figure is a COMMITTED constant of the build, measured by separate rocprofv3 `--pmc FETCH_SIZE`
-    / `--pmc WRITE_SIZE` passes over `bench.py --steps 1` with the guide's gfx950 corrections (tools/profile_round.sh,
+    / `--pmc WRITE_SIZE` passes over `bench.py --steps 1` with the guide's gfx950 corrections (tools/gpu_call.sh pmc,
     tools/pmc_summary.py, tools/pmc_traffic_json.py) and refreshed whenever the kernel changes -- this round's file first,
     the previous round's if this round has not re-collected the workload; (None, None) if absent.  The JSON line names the
     file as `roofline.traffic_source`, so that a reader does not take it for a live measurement."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         tp = os.path.join(ROOT, "profiles", rnd, "pmc_dominant_kernel_traffic.json")
         if not os.path.exists(tp):
             continue

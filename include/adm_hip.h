@@ -29,9 +29,10 @@
 extern "C" {
 #endif
 
-#define ADM_ABI_VERSION 8   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu;
+#define ADM_ABI_VERSION 9   /* 2: adm_conv_args gained in_up / res_up; 3: ksplit / ws; 4: the Inception layer entry points; 5: up_phase; 6: geglu;
                                7: adm_gn_finalize_add gained stats, adm_gn_bwd_finalize gained add / add_stride; the classifier's other heads;
-                               8: adm_conv_args gained fold0 / fold1 / fc0 / fc1 */
+                               8: adm_conv_args gained fold0 / fold1 / fc0 / fc1;
+                               9: adm_conv_args gained out_scale; CU-partitioned streams (adm_stream_create_cumask / _set_cus / _destroy) */
 
 #define ADM_E_ARG      (-1)  /* bad pointer / size / flag combination          */
 #define ADM_E_SHAPE    (-2)  /* shape not supported by the gfx950 tiling       */
@@ -41,6 +42,20 @@ typedef uint16_t adm_bf16;   /* raw bfloat16 bits */
 
 int adm_abi_version(void);
 const char* adm_last_error(void);
+
+/* ---------------------------------------------------------------- CU-partitioned streams
+ * The reference runs eps(x_t) and the guidance gradient one after the other on one CUDA stream
+ * (gaussian_diffusion.py:381-393 condition_score after p_mean_variance); both depend on x_t only, so this build overlaps them
+ * on two streams -- and may give each network its OWN compute units instead of time-sharing all of them:
+ * adm_stream_create_cumask creates a HIP stream whose kernels run only on the CUs named by `mask` (`words` x 32 bits, bit i = CU i
+ * in the driver's numbering: on an 8-XCD device consecutive bits go round-robin over the XCDs) and registers its CU count, which the
+ * persistent kernels (adm_conv) read to size their grids.  adm_stream_set_cus(stream, n) registers / updates (n = 0: forgets) the
+ * budget of a stream created elsewhere.  Results never depend on the partition.                                                  */
+int adm_stream_create_cumask(const uint32_t* mask, int words, void** stream_out);
+int adm_stream_set_cus(void* stream, int ncu);
+int adm_stream_destroy(void* stream);
+/* diagnostic: out_dev[b] = XCC_ID | HW_ID << 8 of block b of a grid of `nblocks` blocks launched on `stream` (which CUs a mask selects) */
+int adm_stream_probe(uint32_t* out_dev, int nblocks, void* stream);
 
 /* ---------------------------------------------------------------- sampler (K9, A7, A10)
  * Per-step scalars = the reference's float64 tables cast to float32 exactly as
@@ -194,6 +209,9 @@ typedef struct adm_conv_args {
                              variant 0 / 5 / 6.  The 1x1 launch, its output tensor and the residual read of these tiles disappear.   */
   const adm_bf16* fold1;
   int32_t fc0, fc1;
+  float out_scale;   /* fp32 NCHW output (out_mode 1) only: out = (acc + bias) * out_scale, applied in fp32 in the epilogue; 0 = 1.0.
+                        The classifier's LAST backward-data conv (the stem's) undoes the static 2^10 scale of an fp16 backward
+                        network here -- in fp32, not in its fp16 weights, where 2^-10 pushed a quarter of them into subnormals */
 } adm_conv_args;
 int adm_conv(const adm_conv_args* args_host, void* stream);
 /* slabs of out_stats for these arguments (0 = fused statistics not offered for this shape / variant). */

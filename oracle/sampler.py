@@ -34,7 +34,7 @@ def _mapped_t(diff: OracleDiffusion, i: int, n: int) -> torch.Tensor:
 
 
 def mean_variance(diff: OracleDiffusion, model_out: torch.Tensor, x: torch.Tensor, i: int,
-                  clip_denoised: bool = True):
+                  clip_denoised: bool = True, denoised_fn: Optional[Callable] = None):
     """model_out [N, C or 2C, H, W] -> dict(mean, variance, log_variance, pred_xstart)."""
     T = diff.tables
     C = x.shape[1]
@@ -59,6 +59,8 @@ def mean_variance(diff: OracleDiffusion, model_out: torch.Tensor, x: torch.Tenso
         x0 = eps_or_x0
     else:
         x0 = _coef(T["sqrt_recip_alphas_cumprod"], i) * x - _coef(T["sqrt_recipm1_alphas_cumprod"], i) * eps_or_x0
+    if denoised_fn is not None:   # process_xstart: denoised_fn first, then the clip (gaussian_diffusion.py:293-298)
+        x0 = denoised_fn(x0)
     if clip_denoised:
         x0 = x0.clamp(-1, 1)
     mean = _coef(T["posterior_mean_coef1"], i) * x0 + _coef(T["posterior_mean_coef2"], i) * x
@@ -71,9 +73,9 @@ def _eps_from_x0(diff, x, i, x0):
 
 
 def ddim_step(diff: OracleDiffusion, model_out, x, i, grad=None, noise=None, eta=0.0,
-              clip_denoised=True):
+              clip_denoised=True, denoised_fn=None):
     T = diff.tables
-    out = mean_variance(diff, model_out, x, i, clip_denoised)
+    out = mean_variance(diff, model_out, x, i, clip_denoised, denoised_fn)
     x0 = out["pred_xstart"]
     ab = _coef(T["alphas_cumprod"], i)
     if grad is not None:  # condition_score: x0 is NOT re-clamped
@@ -90,8 +92,8 @@ def ddim_step(diff: OracleDiffusion, model_out, x, i, grad=None, noise=None, eta
     return {"sample": mean_pred + nz * sigma * noise, "pred_xstart": x0}
 
 
-def ddpm_step(diff: OracleDiffusion, model_out, x, i, grad=None, noise=None, clip_denoised=True):
-    out = mean_variance(diff, model_out, x, i, clip_denoised)
+def ddpm_step(diff: OracleDiffusion, model_out, x, i, grad=None, noise=None, clip_denoised=True, denoised_fn=None):
+    out = mean_variance(diff, model_out, x, i, clip_denoised, denoised_fn)
     mean = out["mean"]
     if grad is not None:  # condition_mean
         mean = mean.float() + out["variance"] * grad.float()
@@ -105,7 +107,7 @@ def ddpm_step(diff: OracleDiffusion, model_out, x, i, grad=None, noise=None, cli
 def sample_loop(diff: OracleDiffusion, model_fn: Callable, x_T: torch.Tensor, *, use_ddim: bool,
                 cond_fn: Optional[Callable] = None, noises: Optional[List[torch.Tensor]] = None,
                 model_kwargs: Optional[dict] = None, clip_denoised: bool = True, eta: float = 0.0,
-                return_all: bool = False):
+                return_all: bool = False, denoised_fn: Optional[Callable] = None):
     """model_fn(x, t_mapped, **kw) -> model_out;  cond_fn(x, t_mapped, **kw) -> grad."""
     kw = model_kwargs or {}
     img = x_T
@@ -119,9 +121,9 @@ def sample_loop(diff: OracleDiffusion, model_fn: Callable, x_T: torch.Tensor, *,
         nz = noises[k] if noises is not None else None
         with torch.no_grad():
             if use_ddim:
-                img = ddim_step(diff, mo, img, i, g, nz, eta, clip_denoised)["sample"]
+                img = ddim_step(diff, mo, img, i, g, nz, eta, clip_denoised, denoised_fn)["sample"]
             else:
-                img = ddpm_step(diff, mo, img, i, g, nz, clip_denoised)["sample"]
+                img = ddpm_step(diff, mo, img, i, g, nz, clip_denoised, denoised_fn)["sample"]
         trail.append(img)
     return trail if return_all else img
 

@@ -46,3 +46,9 @@ def filled(plan, prefix=""):
     shapes = {prefix + k: v for k, v in plan.param_shapes().items()}
     sd = fill_state_dict(shapes)
     return {k[len(prefix):]: v for k, v in sd.items()}
+
+
+def denoised_fn_fixture(x):
+    """The `denoised_fn` of tests/golden/capture_denoised.py (a fixed, smooth, non-linear map of the predicted x_0)."""
+    import torch
+    return 0.8 * x + 0.25 * torch.tanh(3.0 * x)

@@ -139,6 +139,26 @@ def test_forced_world_size_one_group_runs_the_all_gather(tmp_path):
     assert json.loads(str(z["coll"])) == {"op": "all_gather", "backend": "gloo", "world_size": 1, "bytes_per_rank": 8 * (1 + d + d * d), "device": "cpu"}
 
 
+def test_lowrank_frechet_distance_equals_the_covariance_forms():
+    """n < d samples: the n x n eigen form (frechet_distance_lowrank) against the reference's scipy sqrtm formula on np.cov and against
+    the d x d eigen form, float64 on the CPU."""
+    from autodiffusion_amd.fid import frechet_distance_lowrank
+    rng = np.random.default_rng(3)
+    for n, d in ((10, 24), (5, 64), (23, 24)):
+        acts = rng.standard_normal((n, d)) * 0.7 + 0.2
+        ref = FIDStatistics(rng.standard_normal(d) * 0.1, _spd(d, 11))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = float(compute_statistics(acts).frechet_distance(ref))
+        got = frechet_distance_lowrank(torch.from_numpy(acts), torch.from_numpy(ref.mu), torch.from_numpy(ref.sigma))
+        st = compute_statistics(acts)
+        dev = frechet_distance_device(torch.from_numpy(st.mu), torch.from_numpy(st.sigma), torch.from_numpy(ref.mu), torch.from_numpy(ref.sigma))
+        # the d x d form also sums sqrt(|rounding-level eigenvalues|) of the d - n + 1 null directions (~1e-8 each): 1e-7 apart
+        assert abs(got - dev) <= 1e-7 * abs(dev), (n, d, got, dev)
+        assert abs(got - want) <= 1e-6 * abs(want), (n, d, got, want)
+
+
 def test_accumulator_refuses_host_activations():
     from autodiffusion_amd._lib import AdmError
     with pytest.raises(AdmError):
@@ -189,6 +209,37 @@ def test_gpu_frechet_distance_matches_host_sqrtm_at_inception_width():
     t_host = time.time() - t0
     print(f"FID {got:.6f} (device, {t_dev:.2f} s) vs {want:.6f} (host sqrtm, {t_host:.2f} s)")
     assert abs(got - want) <= 1e-6 * abs(want)
+
+
+@pytest.mark.gpu
+def test_gpu_accumulator_takes_the_lowrank_form_for_small_candidates():
+    """keep_rows: a candidate with fewer samples than feature dimensions (BASELINE config 3: 64 images against 2048) gets its FID from
+    the n x n eigenproblem; more rows than announced, or a pooled (multi-rank) call, fall back to the Gram form.  Same value."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    d = 2048
+    g = torch.Generator().manual_seed(4)
+    mix = torch.randn(d, d, generator=g) * d ** -0.5
+    acts = (torch.randn(96, d, generator=g) @ mix) * 0.7 + 0.2
+    ref_acts = ((torch.randn(4096, d, generator=g) @ mix) * 0.8 + 0.25).numpy().astype(np.float64)
+    ref = FIDStatistics(ref_acts.mean(0), np.cov(ref_acts, rowvar=False))
+    gram, low = ActivationAccumulator(d, "cuda:0"), ActivationAccumulator(d, "cuda:0", keep_rows=96)
+    for a in (gram, low):
+        for i in range(0, 96, 32):
+            a.add(acts[i:i + 32].to("cuda:0"))
+    assert low.rows is not None and len(low.rows) == 3 and gram.rows is None
+    want = gram.frechet_distance_device(ref)
+    low.frechet_distance_device(ref)
+    torch.cuda.synchronize()
+    t0 = time.time(); got = low.frechet_distance_device(ref); t_low = time.time() - t0
+    t0 = time.time(); gram.frechet_distance_device(ref); t_gram = time.time() - t0
+    print(f"FID of 96 samples in 2048 dimensions: {got:.6f} (n x n form, {t_low * 1e3:.1f} ms) vs {want:.6f} (d x d form, {t_gram * 1e3:.1f} ms)")
+    assert abs(got - want) <= 1e-7 * abs(want)
+    over = ActivationAccumulator(d, "cuda:0", keep_rows=64)
+    for i in range(0, 96, 32):
+        over.add(acts[i:i + 32].to("cuda:0"))
+    assert over.rows is None and abs(over.frechet_distance_device(ref) - want) <= 1e-12 * abs(want)
 
 
 @pytest.mark.gpu

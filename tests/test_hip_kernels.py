@@ -204,7 +204,26 @@ CONV_CASES = [
     (2, 16, 64, 0, 192, 9, 2, True, False, 7),    # 32x32x16 MFMA kernel
     (1, 32, 64, 32, 384, 9, 0, False, False, 7),  # ... raw prologue, virtual concat, two channel blocks
     (3, 64, 32, 0, 96, 9, 1, True, False, 7),     # ... Cout below one tile: padded columns
+    (3, 8, 160, 0, 96, 1, 1, False, False, 0),    # 128-pixel 1x1 tiles (8x8 maps), 5 chunks: the no-exit loop runs 3 K-steps past the last (chunks % 4 == 1)
+    (2, 8, 224, 0, 64, 1, 0, True, False, 0),     # ... 7 chunks (chunks % 4 == 3), raw prologue, residual
+    (6, 16, 1312, 0, 320, 1, 0, False, False, 0),  # ... the deep staged 1x1 (16x16, K = 41 chunks: % 8 == 1 on the 8-deep weight ring)
 ]
+
+
+def test_conv1x1_pad_steps_read_zero_activations(ops):
+    """The no-exit 1x1 loops run up to 3 (7) K-steps past the tile's last chunk on zero weight fragments; the activation side of
+    those steps must be zeros too: an Inf in the LAST chunk (an overflowed fp16 torso) gives +-Inf at that pixel, as the exact
+    loop does -- not 0 x Inf = NaN from re-reading it."""
+    n, hw, cin, cout = 2, 8, 160, 96
+    x = bf(rnd((n, cin, hw, hw), 1))
+    x[1, cin - 3, 2, 5] = float("inf")          # last 32-channel chunk
+    w = rnd((cout, cin, 1, 1), 2, cin ** -0.5)
+    got = nchw_cpu(ops.conv(nhwc_dev(x), ops.pack_conv_weight(w.to(DEV)), torch.zeros(cout, device=DEV), cout, 1))
+    hit = got[1, :, 2, 5]
+    assert torch.isinf(hit).all() and not torch.isnan(got).any(), (hit, torch.isnan(got).sum())
+    assert torch.equal(torch.sign(hit), torch.sign(bf(w)[:, cin - 3, 0, 0]))
+    got[1, :, 2, 5] = 0
+    assert torch.isfinite(got).all()
 
 
 @pytest.mark.parametrize("case", CONV_CASES)

@@ -218,3 +218,101 @@ def test_graph_cache_grows_with_the_candidates_distinct_skip_sets():
         model.GRAPH_CACHE_MAX = old
         model.GRAPH_CACHE = type(model).GRAPH_CACHE
         model.enable_graph(False)
+
+
+def test_graph_pools_are_bounded_by_bytes_not_only_by_count():
+    """Every captured graph owns a private activation pool (LSUN-256 at batch 64: > 10 GB each, and a layer-skip candidate brings one
+    per distinct skip set): the replay path measures a capture's pool and falls back to eager launches when the candidate's
+    `distinct sets x pool bytes` exceed GRAPH_POOL_FRACTION of the device's HBM (the round-3 advisor's finding: bounded by count
+    alone, 13-32 such pools could exhaust the HBM mid-search).  Results equal the eager path's bitwise either way."""
+    import itertools
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    model, diffusion, _ = _setup_m64()
+    L = model.layer_num
+    steps = sorted(range(40, 40 + 6 * 100, 100))
+    skips = [list(c) for c in itertools.islice(itertools.combinations(range(L), 2), 6)]
+    cand = {"timesteps": steps, "skip_layers": skips}
+    model.enable_graph(False)
+    ev = CandidateEvaluator(model, diffusion, None, image_size=64, use_ddim=True, device=DEV, use_graph=False)
+    ev.set_candidate(cand)
+    want = ev.sample_batch(2, seed=11).clone()
+    evg = CandidateEvaluator(model, diffusion, None, image_size=64, use_ddim=True, device=DEV, use_graph=True)
+    model._packed.__dict__.pop("graphs", None)
+    old_frac, old_seen = model.GRAPH_POOL_FRACTION, model._pool_bytes_seen
+    try:
+        evg.set_candidate(cand)
+        assert torch.equal(evg.sample_batch(2, seed=11), want)
+        rep = model.graph_report()
+        assert rep["cached_graphs"] == 6 and not rep["eager_fallback"] and rep["pool_bytes_largest"] > 0 and model._pool_bytes_seen > 0, rep
+        pool = model._pool_bytes_seen
+        # a budget of 3 such pools: 6 distinct sets do not fit -> the candidate runs eagerly (known BEFORE any capture now)
+        model.GRAPH_POOL_FRACTION = 3.5 * pool / torch.cuda.get_device_properties(0).total_memory
+        evg.set_candidate(cand)
+        assert model._graph_eager and model.graph_report()["eager_fallback"]
+        assert torch.equal(evg.sample_batch(2, seed=11), want)
+        evg.set_candidate({"timesteps": steps[:3], "skip_layers": skips[:3]})      # 3 sets fit again
+        assert not model._graph_eager
+        # unknown pool size (first capture of a model) with a too-small budget: the first capture replays once, then eager
+        model._packed.__dict__.pop("graphs", None)
+        model._pool_bytes_seen = 0
+        model.GRAPH_POOL_FRACTION = 1.5 * pool / torch.cuda.get_device_properties(0).total_memory
+        evg.set_candidate(cand)
+        assert not model._graph_eager
+        assert torch.equal(evg.sample_batch(2, seed=11), want)
+        assert model._graph_eager and len(model._packed.graphs) <= 1
+    finally:
+        model.GRAPH_POOL_FRACTION, model._pool_bytes_seen = old_frac, old_seen
+        model._graph_eager = False
+        model.enable_graph(False)
+
+
+def test_denoised_fn_steps_and_loops_match_the_reference_capture():
+    """`denoised_fn` (gaussian_diffusion.py:258-326 honours it; round 3 raised): applied to the predicted x_0 before the clip, between
+    two launches of the step kernel.  Single steps (the step arithmetic alone: the reference's model output / gradient come from the
+    fp32 oracle, golden-pinned) to 1e-5, and both guided loops through the HIP networks within the loops' bf16 bound."""
+    from helpers import denoised_fn_fixture as dfn
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    from oracle import nets
+    g = golden("sampler_denoised_m64")
+    model, diffusion, clf = _setup_m64()
+    ev = CandidateEvaluator(model, diffusion, clf, image_size=64, use_ddim=True, device=DEV)
+    ev.set_candidate(g["cand"].tolist())
+    d = ev.active_diffusion
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    P, CP = nets.params_from_numpy(filled(plan_m64(dynamic=True))), nets.params_from_numpy(filled(plan_c64()))
+    for idx in (2, 0):
+        t = torch.full((1,), idx, dtype=torch.int64)
+        tm = torch.full((1,), d.timestep_map[idx], dtype=torch.int64)
+        with torch.no_grad():
+            mo = nets.unet_forward(P, plan_m64(dynamic=True), x, tm, y).to(DEV)
+        gr = nets.classifier_grad(CP, plan_c64(), x, tm, y, 1.0).to(DEV)
+        nz = torch.from_numpy(g[f"noise_i{idx}"]).to(DEV)
+        orig = torch.randn_like
+        torch.randn_like = lambda x_: nz
+        try:
+            for guided, cf in (("u", None), ("g", lambda x_, t_, **kw: gr)):
+                for clip in ((True, False) if (idx == 2 and cf is not None) else (True,)):
+                    tag = f"i{idx}_{guided}" + ("" if clip else "_noclip")
+                    o = d.ddim_sample(lambda x_, t_, **kw: mo, x.to(DEV), t.to(DEV), clip_denoised=clip, denoised_fn=dfn, cond_fn=cf, eta=0.3)
+                    for k_, key in (("sample", "sample"), ("pred_xstart", "x0")):
+                        np.testing.assert_allclose(o[k_].cpu().numpy(), g[f"ddim_{tag}_{key}"], rtol=2e-4, atol=2e-5)
+                    o = d.p_sample(lambda x_, t_, **kw: mo, x.to(DEV), t.to(DEV), clip_denoised=clip, denoised_fn=dfn, cond_fn=cf)
+                    for k_, key in (("sample", "sample"), ("pred_xstart", "x0")):
+                        np.testing.assert_allclose(o[k_].cpu().numpy(), g[f"ddpm_{tag}_{key}"], rtol=2e-4, atol=2e-5)
+        finally:
+            torch.randn_like = orig
+    noises = [torch.from_numpy(n).to(DEV) for n in g["noises"]]
+    for use_ddim, name in ((True, "ddim"), (False, "ddpm")):
+        ev = CandidateEvaluator(model, diffusion, clf, image_size=64, use_ddim=use_ddim, device=DEV)
+        ev.set_candidate(g["cand"].tolist())
+        d = ev.active_diffusion
+        it = iter(noises)
+        orig = torch.randn_like
+        torch.randn_like = lambda x_: next(it)
+        try:
+            fn = d.ddim_sample_loop if use_ddim else d.p_sample_loop
+            sample = fn(ev._model_fn, (1, 3, 64, 64), noise=x.to(DEV), clip_denoised=True, denoised_fn=dfn, model_kwargs={"y": y.to(DEV)},
+                        cond_fn=ev._cond_fn, device=torch.device(DEV))
+        finally:
+            torch.randn_like = orig
+        _check(sample, None, g, f"{name}_loop")

@@ -262,3 +262,31 @@ def test_oracle_class_conditional_256_matches_the_reference_capture():
             out = nets.unet_forward(P, plan, T(g["x"]), T(g["t"]), T(g["y"]), skip_layer=skip)[:, :, ::2, ::2]
             r = float((out - T(g[f"{tag}_sub"])).norm() / T(g[f"{tag}_sub"]).norm())
             assert r < 1e-4, (tag, r)
+
+
+def test_denoised_fn_steps_and_loops_match_the_reference_capture():
+    """`denoised_fn` acts on the predicted x_0 before the clip (gaussian_diffusion.py:293-298): single ddim (eta 0.3) / ddpm steps,
+    guided and unguided, clipped and not, and both guided loops against tests/golden/capture_denoised.py's reference outputs."""
+    from helpers import denoised_fn_fixture as dfn
+    g = golden("sampler_denoised_m64")
+    model_fn, cond_fn = _guided_setup()
+    d = schedule.OracleDiffusion(steps=1000, noise_schedule="cosine", learn_sigma=True).reset(g["cand"].tolist())
+    x, y = T(g["x"]), T(g["y"])
+    for idx in (2, 0):
+        t = torch.full((1,), d.timestep_map[idx], dtype=torch.int64)
+        mo = model_fn(x, t, y)
+        grad = cond_fn(x, t, y=y)
+        nz = T(g[f"noise_i{idx}"])
+        for guided, gr in (("u", None), ("g", grad)):
+            for clip in ((True, False) if (idx == 2 and gr is not None) else (True,)):
+                tag = f"i{idx}_{guided}" + ("" if clip else "_noclip")
+                o = sampler.ddim_step(d, mo, x, idx, gr, nz, eta=0.3, clip_denoised=clip, denoised_fn=dfn)
+                np.testing.assert_allclose(o["sample"].numpy(), g[f"ddim_{tag}_sample"], rtol=1e-3, atol=2e-4)
+                np.testing.assert_allclose(o["pred_xstart"].numpy(), g[f"ddim_{tag}_x0"], rtol=1e-3, atol=2e-4)
+                o = sampler.ddpm_step(d, mo, x, idx, gr, nz, clip_denoised=clip, denoised_fn=dfn)
+                np.testing.assert_allclose(o["sample"].numpy(), g[f"ddpm_{tag}_sample"], rtol=1e-3, atol=2e-4)
+                np.testing.assert_allclose(o["pred_xstart"].numpy(), g[f"ddpm_{tag}_x0"], rtol=1e-3, atol=2e-4)
+    noises = [T(n) for n in g["noises"]]
+    for name, ddim in (("ddim", True), ("ddpm", False)):
+        s = sampler.sample_loop(d, model_fn, x, use_ddim=ddim, cond_fn=cond_fn, noises=noises, model_kwargs={"y": y}, denoised_fn=dfn)
+        np.testing.assert_allclose(s.numpy(), g[f"{name}_loop_sample"], rtol=2e-3, atol=1e-3)

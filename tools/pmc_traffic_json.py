@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r03_<tag>/pmc_<workload>_{FETCH,WRITE}_SIZE.csv (tools/profile_round.sh) -> profiles/r03/pmc_dominant_kernel_traffic.json
+"""gpurun_out/<tag>/pmc_<workload>_{FETCH,WRITE}_SIZE.csv (tools/gpu_call.sh pmc <workload>) -> profiles/<round>/pmc_dominant_kernel_traffic.json
 {workload: {kernel, launches, fetch_size_kb_per_launch, write_size_kb_per_launch, hbm_bytes_per_launch}} for the dominant
 kernel of each workload's bench line.  HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE tallies the
 128-byte requests of a 16 B/lane stream at 64 bytes (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
@@ -38,7 +38,7 @@ def main():
                   "hbm_bytes_per_launch": (2 * f + wv) * 1024,
                   "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
                   "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
-                            f"--workload {w} --steps 1 --warmup 0 (tools/profile_round.sh; {os.path.basename(d)})"}
+                            f"--workload {w} --steps 1 --warmup 0 (tools/gpu_call.sh pmc; {os.path.basename(d)})"}
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in res.items()}))
