@@ -316,3 +316,50 @@ def test_denoised_fn_steps_and_loops_match_the_reference_capture():
         finally:
             torch.randn_like = orig
         _check(sample, None, g, f"{name}_loop")
+
+
+def test_single_step_candidate_and_odd_batch_match_the_oracle():
+    """Edge cases of the candidate space: a ONE-step candidate (reset_diffusion's K == 1 quirk: `posterior_log_variance_clipped` holds the raw
+    variance, search_imagenet64_classifier_guidance.py:242-247 -- it feeds the learned-range interpolation of p_sample) and an odd batch
+    (3 images: ragged image groups in every tile of the 8x8 level), guided, both samplers, against the oracle's loops (golden-pinned for
+    the K == 1 tables, tests/test_oracle_golden.py)."""
+    from autodiffusion_amd.evaluate import CandidateEvaluator
+    from oracle import nets, sampler as osm, schedule as osch
+    model, diffusion, clf = _setup_m64()
+    P, CP = nets.params_from_numpy(filled(plan_m64(dynamic=True))), nets.params_from_numpy(filled(plan_c64()))
+    g = torch.Generator().manual_seed(5)
+    x_T, y = torch.randn(3, 3, 64, 64, generator=g), torch.tensor([1, 500, 999])
+    nz = [torch.randn(3, 3, 64, 64, generator=g)]
+    od = osch.OracleDiffusion(steps=1000, noise_schedule="cosine", learn_sigma=True).reset([500])
+    for use_ddim in (True, False):
+        ev = CandidateEvaluator(model, diffusion, clf, image_size=64, use_ddim=use_ddim, device=DEV)
+        ev.set_candidate([500])
+        d = ev.active_diffusion
+        assert d.num_timesteps == 1 and d.timestep_map == [500]
+        it = iter([n.to(DEV) for n in nz])
+        orig = torch.randn_like
+        torch.randn_like = lambda x_: next(it)
+        try:
+            fn = d.ddim_sample_loop if use_ddim else d.p_sample_loop
+            sample = fn(ev._model_fn, (3, 3, 64, 64), noise=x_T.to(DEV), clip_denoised=True, model_kwargs={"y": y.to(DEV)},
+                        cond_fn=ev._cond_fn, device=torch.device(DEV))
+        finally:
+            torch.randn_like = orig
+        ref = osm.sample_loop(od, lambda x_, t_, y=None: nets.unet_forward(P, plan_m64(dynamic=True), x_, t_, y), x_T, use_ddim=use_ddim,
+                              cond_fn=lambda x_, t_, y=None: nets.classifier_grad(CP, plan_c64(), x_, t_, y, 1.0), noises=nz, model_kwargs={"y": y})
+        r = ((sample.cpu() - ref).norm() / ref.norm()).item()
+        print("K = 1,", "ddim" if use_ddim else "ddpm", "batch 3: rel", r)
+        assert torch.isfinite(sample).all() and r < 2.5e-2, r
+        assert d.last_uint8_nhwc.shape == (3, 64, 64, 3)
+        # the batch-of-3 rows equal their own single-image evaluations bitwise (no batch dependence at ragged sizes either)
+        ev1 = CandidateEvaluator(model, diffusion, clf, image_size=64, use_ddim=use_ddim, device=DEV)
+        ev1.set_candidate([500])
+        it = iter([nz[0][2:3].to(DEV)])
+        torch.randn_like = lambda x_: next(it)
+        try:
+            fn1 = ev1.active_diffusion.ddim_sample_loop if use_ddim else ev1.active_diffusion.p_sample_loop
+            s1 = fn1(ev1._model_fn, (1, 3, 64, 64), noise=x_T[2:3].to(DEV), clip_denoised=True, model_kwargs={"y": y[2:3].to(DEV)},
+                     cond_fn=ev1._cond_fn, device=torch.device(DEV))
+        finally:
+            torch.randn_like = orig
+        assert torch.equal(s1, sample[2:3])
