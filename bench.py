@@ -1145,6 +1145,12 @@ def main():
             sub.workload, sub.batch, sub.images, sub.merge_batches, sub.graph, sub.with_fid = name, None, None, 0, False, False
             sub.skip_layers, sub.sampler_steps, sub.class_cond, sub.conv_breakdown, sub.no_cpu_baseline = None, 0, False, False, True
             sub.steps, sub.warmup = SECONDARY_STEPS.get(name, (2, 1))
+            if name == "adm128":
+                # what a search on this model launches: get_cand_fid merges the reference's memory-driven batches of 32 up to the
+                # 128-image pass cap (evaluate.merge_policy; bitwise the same images) -- the line's workload string says so;
+                # `--workload adm128` on its own times ONE reference batch per pass
+                from autodiffusion_amd.evaluate import merge_policy
+                sub.merge_batches = merge_policy(128, 32)[0]
             gc.collect()
             torch.cuda.empty_cache()
             t0 = time.perf_counter()

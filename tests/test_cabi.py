@@ -42,6 +42,14 @@ def test_argument_errors_surface_as_exceptions_without_a_gpu():
     assert lib.adm_pack_u8_nhwc(None, None, 1, 3, 8, 8, None) == -1
     co = _lib.StepCoefs()
     assert lib.adm_ddim_step(None, None, None, None, None, None, None, 1, 3, 8, 8, C.byref(co), None) == -1
+    # the CU-partition table is host state: registering / forgetting a stream's CU budget needs no GPU
+    fake = C.c_void_p(0x1000)
+    assert lib.adm_stream_set_cus(fake, 96) == 0 and lib.adm_stream_set_cus(fake, 64) == 0 and lib.adm_stream_set_cus(fake, 0) == 0
+    assert lib.adm_stream_set_cus(fake, -1) == -1 and b"ncu" in lib.adm_last_error()
+    out = C.c_void_p()
+    assert lib.adm_stream_create_cumask(None, 8, C.byref(out)) == -1
+    empty = (C.c_uint32 * 8)()
+    assert lib.adm_stream_create_cumask(empty, 8, C.byref(out)) == -1 and b"empty mask" in lib.adm_last_error()
 
 
 def test_header_is_plain_c_and_links_from_a_c_client(tmp_path):
