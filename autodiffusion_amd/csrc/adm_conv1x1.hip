@@ -440,6 +440,17 @@ int adm_conv1x1_resident_cfg(const adm_conv_args* a, int* wm_out) {
   const int lim = 160 * 1024;
   if (hw % 128 == 0 && c1_lds_bytes<128>(k) <= lim) return 128;
   if (c1_lds_bytes<64>(k) <= lim) return 64;
+  // Deep projections of the 16x16 / 8x8 levels (K >= 1280: SD v1's 1280-wide transformer blocks) on 32-PIXEL resident tiles: the
+  // [32][K] tile is fetched once by all 512 threads and the K loop runs from LDS with the weights three K-steps ahead, where the
+  // staged kernel streams the K loop chunk by chunk through registers and a barrier.  Built, parity-tested (variant 10 takes these
+  // shapes explicitly) and MEASURED (round 4, profiles/r04/ab_sd_bm32.log): alone on the chip it wins where a grid entry walks ONE
+  // 384-wide Cout block (tools/c1_bench.py SHAPESET=sd at 6 latents: 1280 -> 1280 + residual 16.4 vs 18.7 us, with a GroupNorm prologue
+  // 15.6 vs 26.8 us) and loses on wide outputs (4 x the weight traffic of a 128-pixel tile: qkv 1280 -> 3840 35.8 vs 23.5 us) -- and
+  // inside the real evaluation, two half batches on two streams, even the narrow-output rule is 0.6 % SLOWER (65.7 vs 66.2 latents/s):
+  // its L2 weight streaming lands on the other stream's kernels.  So the automatic choice leaves these shapes on the staged kernel;
+  // ADM_C1_BM32=1 opts in (outputs <= 1536 wide), by shape only.
+  static const bool bm32 = getenv("ADM_C1_BM32") != nullptr;
+  if (k >= 1280 && hw <= 256 && hw % 32 == 0 && a->cout > 192 && (a->variant == 10 || (bm32 && a->cout <= 1536)) && c1_lds_bytes<32>(k) <= lim) return 32;
   return 0;
 }
 
@@ -499,9 +510,11 @@ int adm_conv1x1_resident_launch(const adm_conv_args* a, void* stream) {
   const unsigned segk = (unsigned)kk / 8;
   k.rcp_seg = (unsigned)(((1ull << 32) + segk - 1) / segk);
   hipStream_t s = (hipStream_t)stream;
-  const int smem = bm == 128 ? c1_lds_bytes<128>(kk) : c1_lds_bytes<64>(kk);
+  const int smem = bm == 128 ? c1_lds_bytes<128>(kk) : (bm == 64 ? c1_lds_bytes<64>(kk) : c1_lds_bytes<32>(kk));
   if (a->geglu)   // raw input, no residual, no statistics, 384-wide Cout blocks (checked by adm_conv1x1_resident_cfg)
-    return bm == 128 ? launch_c1<128, 0, true, 1, true>(k, smem, s) : launch_c1<64, 0, true, 1, true>(k, smem, s);
+    return bm == 128 ? launch_c1<128, 0, true, 1, true>(k, smem, s)
+                     : (bm == 64 ? launch_c1<64, 0, true, 1, true>(k, smem, s) : launch_c1<32, 0, true, 1, true>(k, smem, s));
   if (bm == 128) return wm == 1 ? launch_c1_cfg<128, 1>(a, k, smem, s) : launch_c1_cfg<128, 2>(a, k, smem, s);
+  if (bm == 32) return launch_c1_cfg<32, 1>(a, k, smem, s);   // cout > 192 (adm_conv1x1_resident_cfg): always the 1 x 8 wave layout
   return wm == 1 ? launch_c1_cfg<64, 1>(a, k, smem, s) : launch_c1_cfg<64, 2>(a, k, smem, s);
 }

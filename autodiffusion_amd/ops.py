@@ -485,6 +485,23 @@ def geglu_interleave(w, b):
     return wi.contiguous(), bi.contiguous()
 
 
+_GEGLU_OK = {}
+
+
+def geglu_fusable(x, cout: int) -> bool:
+    """Does adm_conv take conv(x, ..., cout, 1, geglu=True)?  The GEGLU epilogue lives on the resident-tile 1x1 kernel only, and
+    whether that kernel takes a shape is the library's decision (LDS budget of the pixel tile, its A/B switches): asked once per
+    (map, channels, dtype) through adm_conv_pick_variant -- by shape, never by batch."""
+    n, h, w, c = x.shape
+    key = (h, w, c, cout, x.dtype)
+    ok = _GEGLU_OK.get(key)
+    if ok is None:
+        a = ConvArgs()
+        a.n, a.h, a.w, a.c0, a.c1, a.cout, a.taps, a.geglu = 1, h, w, c, 0, cout, 1, 1
+        ok = _GEGLU_OK[key] = _L(x).adm_conv_pick_variant(C.byref(a)) == 10
+    return ok
+
+
 def geglu(u):
     """bf16 [..., 2*I] -> bf16 [..., I]: u[..., :I] * gelu(u[..., I:])."""
     inner = u.shape[-1] // 2

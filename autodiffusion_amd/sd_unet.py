@@ -221,7 +221,7 @@ class UNetModel(HipModule):
             h = ops.conv(a.view(n, hh, ww, hd), L["o2"], L["o2b"], inner, 1, res=h, ksplit=self._ks1(x, hd, inner))
             # gated feed-forward
             y = ops.layernorm(h, *L["norm3"])
-            if self.fuse_geglu and "ff1g" in L and t % 64 == 0:
+            if self.fuse_geglu and "ff1g" in L and t % 64 == 0 and ops.geglu_fusable(y, 8 * inner):
                 gl = ops.conv(y, L["ff1g"], L["ff1gb"], 8 * inner, 1, geglu=True)    # [n, hh, ww, 4 * inner]: u never exists
             else:
                 gl = ops.geglu(ops.conv(y, L["ff1"], L["ff1b"], 8 * inner, 1))

@@ -207,6 +207,10 @@ CONV_CASES = [
     (3, 8, 160, 0, 96, 1, 1, False, False, 0),    # 128-pixel 1x1 tiles (8x8 maps), 5 chunks: the no-exit loop runs 3 K-steps past the last (chunks % 4 == 1)
     (2, 8, 224, 0, 64, 1, 0, True, False, 0),     # ... 7 chunks (chunks % 4 == 3), raw prologue, residual
     (6, 16, 1312, 0, 320, 1, 0, False, False, 0),  # ... the deep staged 1x1 (16x16, K = 41 chunks: % 8 == 1 on the 8-deep weight ring)
+    (3, 16, 1280, 0, 640, 1, 1, False, False, 10),  # resident-tile kernel on 32-PIXEL tiles (K >= 1280 at 16x16 / 8x8; explicit: variant 10): GroupNorm-affine prologue, ragged last Cout block, wave-private epilogue
+    (5, 8, 1280, 0, 1280, 1, 0, True, False, 10),   # ... 8x8 maps (two tiles per image), residual: the block epilogue
+    (2, 16, 1024, 256, 1408, 1, 2, False, False, 10),  # ... virtual concat (K = 1280), SiLU prologue, 4 Cout blocks (the last ragged)
+    (2, 16, 1280, 0, 1920, 1, 0, False, False, 10),   # ... 5 Cout blocks
 ]
 
 
@@ -396,7 +400,9 @@ def test_attention_softmax_is_stable_for_large_logits(ops):
 @pytest.mark.parametrize("n,hw,cin,cout,taps,variant", [(3, 16, 64, 192, 9, 0), (2, 32, 32, 96, 9, 0), (5, 8, 64, 192, 9, 0),
                                                          (2, 64, 32, 64, 1, 0), (2, 16, 32, 128, 9, 6), (3, 8, 64, 128, 1, 0),
                                                          (2, 16, 64, 384, 1, 0), (3, 8, 128, 256, 1, 0), (2, 16, 64, 192, 1, 10),  # resident-tile 1x1
-                                                         (3, 16, 1280, 320, 1, 0)])   # deep 1x1 at 16x16: 128-pixel tiles, four slabs per image
+                                                         (3, 16, 1280, 320, 1, 0),     # deep 1x1 at 16x16: the staged kernel's 128-pixel tiles, four slabs per image
+                                                         (3, 16, 1280, 320, 1, 10),    # ... resident 32-pixel tiles (explicit), eight slabs per image
+                                                         (2, 8, 1280, 384, 1, 10)])    # ... 8x8 maps: two 32-pixel tiles per image
 def test_conv_fused_output_statistics_feed_groupnorm(ops, n, hw, cin, cout, taps, variant):
     """The sums accumulated in the conv epilogue must give the same GroupNorm affine as a separate pass."""
     k = 3 if taps == 9 else 1
