@@ -154,3 +154,16 @@ def test_bench_merged_batches_line():
     assert out["config"]["batches_per_pass"] == 3 and out["config"]["global_batch"] == 12
     assert abs(out["value"] - 12 / (out["ms_per_step"] * 1e-3)) <= 0.02 * out["value"]
     assert out["output_check"]["finite"] is True and out["output_check"]["u8_shape"] == [4, 64, 64, 3]
+
+
+def test_more_nccl_ranks_than_gpus_is_refused_with_a_reason():
+    """`--gpus 2` with the nccl backend on a box with ONE GPU: RCCL takes one rank per device, so every rank exits at once with a
+    message that names the cause (not a hang inside communicator set-up); gloo is the rehearsal backend."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has a GPU per rank")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert r.returncode != 0
+    assert "RCCL takes one rank per device" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
